@@ -1,0 +1,208 @@
+/*
+ * include/ocd.h -- C ABI of the MI355X batched MPC planner ("ocd" = optimal
+ * control design; the reference is avikj/L4DC-MPC-OCD).
+ *
+ * The reference has NO native / FFI boundary: it is pure Python on TensorFlow
+ * and its seam is Python-level.  Every entry point below therefore names the
+ * reference *Python* interface it replaces (file:line relative to the
+ * reference tree); the ctypes binding a maintainer would add on the reference
+ * side is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes, no torch / HIP types in signatures;
+ *   - every data pointer of the device entry points is a DEVICE pointer
+ *     (e.g. torch-ROCm tensor.data_ptr()); the caller owns every buffer, the
+ *     library owns only the opaque scenario handle;
+ *   - `hip_stream` is a hipStream_t passed as void* (NULL = default stream);
+ *     calls are asynchronous on that stream, the caller synchronises;
+ *   - return 0 on success, negative ocd_status on error; the message is
+ *     available from ocd_last_error() (thread-local); nothing throws across
+ *     the boundary;
+ *   - all arithmetic is IEEE binary32 with the operation order documented in
+ *     DESIGN.md section 3 ("arithmetic contract").
+ */
+#ifndef OCD_H
+#define OCD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OCD_ABI_VERSION 1
+
+#define OCD_MAX_CARS 4      /* ego + up to 3 scripted cars                    */
+#define OCD_MAX_OTHERS 3
+#define OCD_MAX_LANES 4
+#define OCD_MAX_FEATURES 8  /* D = n_lanes + 4                                */
+#define OCD_MAX_PLAN 8      /* scripted controls of a FixedPlanCar            */
+#define OCD_MAX_SAMPLES 4   /* world.reset() repetitions per (candidate,init) */
+#define OCD_MAX_HORIZON 32  /* planning horizon H handled by the HIP path     */
+#define OCD_MAX_CTRL_INITS 6
+
+typedef enum ocd_status {
+    OCD_OK = 0,
+    OCD_ERR_INVALID_ARG = -1,
+    OCD_ERR_UNSUPPORTED = -2,   /* configuration outside the compiled kernels */
+    OCD_ERR_HIP = -3,           /* a HIP runtime call failed                  */
+    OCD_ERR_NO_DEVICE = -4
+} ocd_status;
+
+/* Which car.reward_fn the planning car uses. */
+typedef enum ocd_reward_kind {
+    /* ThreeLaneTestCar.features + LinearRewardCar.reward_fn
+     * (experiments/merging.py:32-83, interact_drive/car/linear_reward_car.py:49-55):
+     * D = n_lanes + 4 features, r = sum_d w_d * phi_d. */
+    OCD_REWARD_LANE_FEATURES = 0,
+    /* TargetSpeedPlannerCar.reward_fn = -(v - target_speed)^2
+     * (interact_drive/planner/tests/targetSpeedRewardMaximizerCar.py:49-57);
+     * only used to pin the planner against the reference's own known-answer
+     * tests (interact_drive/planner/tests/test_naivePlanner.py:21-63). */
+    OCD_REWARD_TARGET_SPEED = 1
+} ocd_reward_kind;
+
+/*
+ * Static description of one driving scenario: everything the reference's
+ * scenario factories hard-code (interact_drive/reward_design/mpc_ord.py:162-207,
+ * experiments/local_opt_scenario.py:6-55, experiments/replanning_world.py:45-95,
+ * experiments/merging.py:86-99) plus the planner arguments
+ * (interact_drive/planner/naive_planner.py:19-30).  Car 0 is the planning
+ * ("ego") car; cars 1..n_cars-1 are scripted.
+ */
+typedef struct ocd_scenario_desc {
+    int32_t abi_version;        /* OCD_ABI_VERSION */
+    int32_t reward_kind;        /* ocd_reward_kind */
+    int32_t n_cars;             /* C in [1, OCD_MAX_CARS] */
+    int32_t n_lanes;            /* L in [0, OCD_MAX_LANES]; world.lanes (world.py:143-159) */
+    int32_t horizon;            /* H, NaivePlanner.horizon */
+    int32_t n_iter;             /* I, SGD steps per control initialisation (naive_planner.py:20) */
+    int32_t extra_inits;        /* 0: K=3 inits, 1: K=6 (naive_planner.py:107-116) */
+    int32_t check_plans;        /* PlannerCar.check_plans (planner_car.py:58-80) */
+    int32_t episode_len;        /* T, MPC_ORD.designer_horizon (mpc_ord.py:95) */
+    int32_t n_samples;          /* S, MPC_ORD.num_samples (mpc_ord.py:87) */
+    int32_t teleport_step;      /* ReplanningCarWorld.critical_t (replanning_world.py:18,32); 0 = never */
+    int32_t teleport_car[OCD_MAX_SAMPLES]; /* car index moved away in sample s (replanning_world.py:24-27,33) */
+    float teleport_state[4];    /* (10,0,0,0) (replanning_world.py:34) */
+
+    float dt;                   /* CarWorld.dt (world.py:19) */
+    float dt_sq;                /* fp32(dt ** 2): the reference squares the Python float in double
+                                 * before the fp32 multiply (simulation_utils.py:14) */
+    float learning_rate;        /* SGD learning rate (naive_planner.py:20,28) */
+    float ego_friction;         /* Car.friction of the planning car (car.py:33) */
+    float target_speed;         /* ThreeLaneTestCar.target_speed (merging.py:29) */
+    float lane_center[OCD_MAX_LANES]; /* StraightLane.p[0] per lane (world.py:150-151,157-158) */
+    float fence_lo;             /* fp32(0.05*num_lanes - 0.05): threshold - width (math_utils.py:89, merging.py:80) */
+    float fence_width;          /* 0.05 */
+    float fence_shape;          /* c / width = 100 (math_utils.py:85) */
+    float bump_half_x;          /* 0.08 (merging.py:72) */
+    float bump_half_y;          /* 0.15 (merging.py:73) */
+
+    float other_init[OCD_MAX_OTHERS][4];      /* scripted cars' init_state */
+    float other_friction[OCD_MAX_OTHERS];     /* 0 FixedVelocityCar (fixed_velocity_car.py:23), 0.2 FixedPlanCar */
+    int32_t other_plan_len[OCD_MAX_OTHERS];   /* len(FixedPlanCar.plan); 0 = always other_default */
+    float other_plan[OCD_MAX_OTHERS][OCD_MAX_PLAN][2];
+    float other_default[OCD_MAX_OTHERS][2];   /* FixedPlanCar.default_control / FixedControlCar.control */
+
+    float designer_weights[OCD_MAX_FEATURES]; /* MPC_ORD.designer_weights, fp32, already normalised (mpc_ord.py:24) */
+} ocd_scenario_desc;
+
+typedef struct ocd_scenario ocd_scenario; /* opaque: validated descriptor + device-side constants */
+
+/* Library / device probes. */
+int32_t ocd_abi_version(void);
+/* Number of visible HIP devices, or a negative ocd_status. */
+int32_t ocd_device_count(void);
+/* Thread-local description of the last error returned on this thread. */
+const char *ocd_last_error(void);
+
+/* Validate a descriptor and build the handle the kernels read their constants
+ * from.  Replaces the reference's scenario factories + NaivePlanner.__init__
+ * (naive_planner.py:19-30, planner_car.py:49-52). */
+int32_t ocd_scenario_create(const ocd_scenario_desc *desc, ocd_scenario **out);
+void ocd_scenario_destroy(ocd_scenario *scn);
+
+/*
+ * One receding-horizon plan for each of B independent world states.
+ * Replaces NaivePlanner.generate_plan(init_state, weights, other_controls)
+ * (naive_planner.py:81-164): K control initialisations x n_iter plain-SGD
+ * ascent steps on the H x 2 controls, one more evaluation of the objective,
+ * first-index argmin of the loss.
+ *
+ *   world_state  [B, C, 4]   (x, y, v, heading) per car, car 0 = ego
+ *   weights      [B, D] when weights_per_problem != 0, else [D] shared;
+ *                ignored (may be NULL) for OCD_REWARD_TARGET_SPEED
+ *   other_plans  [C-1, H, 2] controls the planner assumes for the scripted
+ *                cars (naive_planner.py:53-59), or NULL = constant velocity
+ *                (naive_planner.py:60-65)
+ *   plans_out    [B, H, 2]   the selected control sequence
+ *   best_loss_out[B]         -R of the selected initialisation   (may be NULL)
+ *   best_init_out[B]         index k of the selected initialisation (may be NULL)
+ *   all_plans_out[B, K, H, 2], all_losses_out [B, K]  per-initialisation
+ *                results before the argmin (may be NULL; used by parity tests)
+ */
+int32_t ocd_plan_batch(const ocd_scenario *scn,
+                       const float *world_state,
+                       const float *weights, int32_t weights_per_problem,
+                       const float *other_plans,
+                       float *plans_out, float *best_loss_out, int32_t *best_init_out,
+                       float *all_plans_out, float *all_losses_out,
+                       int64_t B, void *hip_stream);
+
+/*
+ * Full receding-horizon episodes: for every (candidate p, init n, sample s)
+ * with flat index e = (p*N + n)*S + s in [ep_begin, ep_end): reset the world,
+ * then T times { optional teleport; score the PRE-step state with the
+ * designer weights; plan; apply the first planned control through the real
+ * dynamics; step the scripted cars }.  Replaces MPC_ORD.eval_weights_for_init
+ * (mpc_ord.py:67-106) driven over CarWorld.step (world.py:79-109),
+ * PlannerCar._get_next_control (planner_car.py:54-85) and Car.step
+ * (car.py:76-87).
+ *
+ *   init_states  [N, 4]  ego initial states (fp32)
+ *   cand_weights [P, D]  planner weights per candidate, fp32, ALREADY
+ *                normalised the way the reference does it on the host
+ *                (mpc_ord.py:71,120, linear_reward_car.py:47)
+ *   returns_out  [ep_end-ep_begin]           fp32 sample_reward per episode
+ *   traj_out     [ep_end-ep_begin, T+1, C, 4] world states (may be NULL)
+ *   ctrl_out     [ep_end-ep_begin, T, 2]      applied ego controls (may be NULL)
+ */
+int32_t ocd_rollout_episodes(const ocd_scenario *scn,
+                             const float *init_states,
+                             const float *cand_weights,
+                             int64_t P, int64_t N,
+                             int64_t ep_begin, int64_t ep_end,
+                             float *returns_out, float *traj_out, float *ctrl_out,
+                             void *hip_stream);
+
+/*
+ * Reward features and reward of B world states (no planning).  Replaces
+ * ThreeLaneTestCar.features / LinearRewardCar.reward_fn evaluated on a grid,
+ * e.g. the visualiser's heat map (interact_drive/visualizer.py:211-238).
+ *   world_state [B, C, 4]; weights [D] ; feats_out [B, D] (may be NULL);
+ *   reward_out [B] (may be NULL).
+ */
+int32_t ocd_reward_batch(const ocd_scenario *scn,
+                         const float *world_state, const float *weights,
+                         float *feats_out, float *reward_out,
+                         int64_t B, void *hip_stream);
+
+/* Device exp / sin / cos of n floats: lets the tests prove the device math is
+ * bit-identical to the oracle's restatement.  in, exp_out, sin_out, cos_out: [n]. */
+int32_t ocd_debug_math(const float *in, float *exp_out, float *sin_out, float *cos_out,
+                       int64_t n, void *hip_stream);
+
+/* Timing helper used by bench.py: runs `reps` back-to-back launches of
+ * ocd_rollout_episodes on `hip_stream`, bracketed by HIP events recorded on
+ * that same stream, and returns the mean milliseconds per launch in *ms_out
+ * (host pointer).  Synchronises the stream. */
+int32_t ocd_time_rollout(const ocd_scenario *scn,
+                         const float *init_states, const float *cand_weights,
+                         int64_t P, int64_t N, int64_t ep_begin, int64_t ep_end,
+                         float *returns_out, int32_t reps, float *ms_out,
+                         void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCD_H */

@@ -1,0 +1,140 @@
+"""ctypes mirror of include/ocd.h and the loader of the HIP C-ABI library.
+
+The product path never falls back to a CPU implementation: if the HIP library
+is missing or does not export a symbol declared in include/ocd.h, loading
+raises.  (The CPU oracle under oracle/ is test infrastructure and is never
+imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+OCD_ABI_VERSION = 1
+OCD_MAX_CARS = 4
+OCD_MAX_OTHERS = 3
+OCD_MAX_LANES = 4
+OCD_MAX_FEATURES = 8
+OCD_MAX_PLAN = 8
+OCD_MAX_SAMPLES = 4
+OCD_MAX_HORIZON = 32
+OCD_MAX_CTRL_INITS = 6
+
+OCD_OK = 0
+OCD_ERR_INVALID_ARG = -1
+OCD_ERR_UNSUPPORTED = -2
+OCD_ERR_HIP = -3
+OCD_ERR_NO_DEVICE = -4
+
+OCD_REWARD_LANE_FEATURES = 0
+OCD_REWARD_TARGET_SPEED = 1
+
+
+class ScenarioDesc(C.Structure):
+    """struct ocd_scenario_desc (include/ocd.h); field order is the ABI."""
+
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("reward_kind", C.c_int32),
+        ("n_cars", C.c_int32),
+        ("n_lanes", C.c_int32),
+        ("horizon", C.c_int32),
+        ("n_iter", C.c_int32),
+        ("extra_inits", C.c_int32),
+        ("check_plans", C.c_int32),
+        ("episode_len", C.c_int32),
+        ("n_samples", C.c_int32),
+        ("teleport_step", C.c_int32),
+        ("teleport_car", C.c_int32 * OCD_MAX_SAMPLES),
+        ("teleport_state", C.c_float * 4),
+        ("dt", C.c_float),
+        ("dt_sq", C.c_float),
+        ("learning_rate", C.c_float),
+        ("ego_friction", C.c_float),
+        ("target_speed", C.c_float),
+        ("lane_center", C.c_float * OCD_MAX_LANES),
+        ("fence_lo", C.c_float),
+        ("fence_width", C.c_float),
+        ("fence_shape", C.c_float),
+        ("bump_half_x", C.c_float),
+        ("bump_half_y", C.c_float),
+        ("other_init", (C.c_float * 4) * OCD_MAX_OTHERS),
+        ("other_friction", C.c_float * OCD_MAX_OTHERS),
+        ("other_plan_len", C.c_int32 * OCD_MAX_OTHERS),
+        ("other_plan", ((C.c_float * 2) * OCD_MAX_PLAN) * OCD_MAX_OTHERS),
+        ("other_default", (C.c_float * 2) * OCD_MAX_OTHERS),
+        ("designer_weights", C.c_float * OCD_MAX_FEATURES),
+    ]
+
+    @property
+    def n_features(self) -> int:
+        return self.n_lanes + 4 if self.reward_kind == OCD_REWARD_LANE_FEATURES else 0
+
+    @property
+    def n_ctrl_inits(self) -> int:
+        return 6 if self.extra_inits else 3
+
+
+# Every symbol include/ocd.h declares: (name, restype, argtypes)
+_F = C.POINTER(C.c_float)
+_I = C.POINTER(C.c_int32)
+_VP = C.c_void_p
+HIP_SYMBOLS = [
+    ("ocd_abi_version", C.c_int32, []),
+    ("ocd_device_count", C.c_int32, []),
+    ("ocd_last_error", C.c_char_p, []),
+    ("ocd_scenario_create", C.c_int32, [C.POINTER(ScenarioDesc), C.POINTER(_VP)]),
+    ("ocd_scenario_destroy", None, [_VP]),
+    ("ocd_plan_batch", C.c_int32,
+     [_VP, _VP, _VP, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, _VP]),
+    ("ocd_rollout_episodes", C.c_int32,
+     [_VP, _VP, _VP, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _VP, _VP, _VP, _VP]),
+    ("ocd_reward_batch", C.c_int32, [_VP, _VP, _VP, _VP, _VP, C.c_int64, _VP]),
+    ("ocd_debug_math", C.c_int32, [_VP, _VP, _VP, _VP, C.c_int64, _VP]),
+    ("ocd_time_rollout", C.c_int32,
+     [_VP, _VP, _VP, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _VP, C.c_int32,
+      C.POINTER(C.c_float), _VP]),
+]
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(_PKG_DIR, "csrc", "libocd_hip.so")
+
+_lib: Optional[C.CDLL] = None
+
+
+class OcdError(RuntimeError):
+    """A C-ABI call returned a negative ocd_status."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(f"ocd status {status}: {message}")
+        self.status = status
+
+
+def load_hip_library(path: Optional[str] = None) -> C.CDLL:
+    """dlopen libocd_hip.so and bind every declared symbol.  Raises if absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or HIP_LIB_PATH
+    if not os.path.exists(p):
+        raise FileNotFoundError(
+            f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(the MI355X planner has no CPU fallback)")
+    lib = C.CDLL(p)
+    for name, restype, argtypes in HIP_SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    got = lib.ocd_abi_version()
+    if got != OCD_ABI_VERSION:
+        raise RuntimeError(f"libocd_hip.so ABI {got} != header ABI {OCD_ABI_VERSION}")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(lib: C.CDLL, status: int) -> None:
+    if status != OCD_OK:
+        msg = lib.ocd_last_error()
+        raise OcdError(status, msg.decode() if msg else "")

@@ -1,0 +1,184 @@
+"""ctypes binding of the CPU oracle (oracle/libocd_oracle.so).  TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+import sys
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+from l4dc_mpc_ocd_amd.abi import ScenarioDesc  # noqa: E402  (struct layout only)
+
+_F = C.POINTER(C.c_float)
+_I = C.POINTER(C.c_int32)
+_D = C.POINTER(ScenarioDesc)
+
+
+def _fp(a):
+    return None if a is None else a.ctypes.data_as(_F)
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(_I)
+
+
+class Oracle:
+    def __init__(self, path: str):
+        self.lib = lib = C.CDLL(path)
+        for n in ("ocd_oracle_expf", "ocd_oracle_sinf", "ocd_oracle_cosf"):
+            getattr(lib, n).restype = C.c_float
+            getattr(lib, n).argtypes = [C.c_float]
+        lib.ocd_oracle_f.restype = C.c_float
+        lib.ocd_oracle_f.argtypes = [C.c_float, C.c_float]
+        lib.ocd_oracle_smooth_threshold.restype = C.c_float
+        lib.ocd_oracle_smooth_threshold.argtypes = [C.c_float] * 4
+        lib.ocd_oracle_smooth_bump.restype = C.c_float
+        lib.ocd_oracle_smooth_bump.argtypes = [C.c_float] * 3
+        lib.ocd_oracle_dynamics_step.restype = None
+        lib.ocd_oracle_dynamics_step.argtypes = [_F, _F, C.c_float, C.c_float, C.c_float, _F]
+        lib.ocd_oracle_reward.restype = C.c_float
+        lib.ocd_oracle_reward.argtypes = [_D, _F, _F, _F, _F]
+        lib.ocd_oracle_mpc_reward.restype = C.c_float
+        lib.ocd_oracle_mpc_reward.argtypes = [_D, _F, _F, _F, _F, _F, _F]
+        lib.ocd_plan_batch_cpu.restype = C.c_int32
+        lib.ocd_plan_batch_cpu.argtypes = [_D, _F, _F, C.c_int32, _F, _F, _F, _I, _F, _F, C.c_int64, C.c_int32]
+        lib.ocd_rollout_episodes_cpu.restype = C.c_int32
+        lib.ocd_rollout_episodes_cpu.argtypes = [_D, _F, _F, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                                 _F, _F, _F, C.c_int32]
+        lib.ocd_reward_batch_cpu.restype = C.c_int32
+        lib.ocd_reward_batch_cpu.argtypes = [_D, _F, _F, _F, _F, C.c_int64]
+        lib.ocd_oracle_uses_libm.restype = C.c_int32
+
+    # --- scalar primitives -------------------------------------------------
+    def expf(self, x): return float(self.lib.ocd_oracle_expf(float(x)))
+    def sinf(self, x): return float(self.lib.ocd_oracle_sinf(float(x)))
+    def cosf(self, x): return float(self.lib.ocd_oracle_cosf(float(x)))
+    def f(self, x, shape=5.0): return float(self.lib.ocd_oracle_f(float(x), float(shape)))
+
+    def smooth_threshold(self, x, threshold, width, c=5.0):
+        lo = np.float32(threshold - width)
+        return float(self.lib.ocd_oracle_smooth_threshold(float(x), float(lo), float(width), float(np.float32(c / width))))
+
+    def smooth_bump(self, x, start, end):
+        return float(self.lib.ocd_oracle_smooth_bump(float(x), float(start), float(end)))
+
+    def exp_array(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        return np.array([self.lib.ocd_oracle_expf(float(v)) for v in x], dtype=np.float32)
+
+    def dynamics_step(self, state, control, dt, friction):
+        st = np.ascontiguousarray(state, dtype=np.float32)
+        u = np.ascontiguousarray(control, dtype=np.float32)
+        out = np.empty(4, dtype=np.float32)
+        self.lib.ocd_oracle_dynamics_step(_fp(st), _fp(u), float(dt), float(np.float32(float(dt) ** 2)),
+                                          float(friction), _fp(out))
+        return out
+
+    # --- reward / objective ----------------------------------------------
+    def reward(self, desc, world_state, weights, want_grad=False):
+        ws = np.ascontiguousarray(world_state, dtype=np.float32)
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float32)
+        feats = np.zeros(max(desc.n_features, 1), dtype=np.float32)
+        grad = np.zeros(4, dtype=np.float32) if want_grad else None
+        r = self.lib.ocd_oracle_reward(C.byref(desc), _fp(ws), _fp(w), _fp(feats), _fp(grad))
+        return np.float32(r), feats[: desc.n_features], grad
+
+    def mpc_reward(self, desc, world_state, weights, controls, other_plans=None, want_grad=True):
+        ws = np.ascontiguousarray(world_state, dtype=np.float32)
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float32)
+        u = np.ascontiguousarray(controls, dtype=np.float32)
+        op = None if other_plans is None else np.ascontiguousarray(other_plans, dtype=np.float32)
+        H = desc.horizon
+        grad = np.zeros((H, 2), dtype=np.float32) if want_grad else None
+        traj = np.zeros((H, 4), dtype=np.float32)
+        r = self.lib.ocd_oracle_mpc_reward(C.byref(desc), _fp(ws), _fp(w), _fp(u), _fp(op), _fp(grad), _fp(traj))
+        return np.float32(r), grad, traj
+
+    # --- CPU twins of the device entry points ----------------------------
+    def plan_batch(self, desc, world_state, weights, other_plans=None, n_threads=0):
+        ws = np.ascontiguousarray(world_state, dtype=np.float32)
+        C_, H, K = desc.n_cars, desc.horizon, desc.n_ctrl_inits
+        ws = ws.reshape(-1, C_, 4)
+        B = ws.shape[0]
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float32)
+        per = int(w is not None and w.ndim == 2)
+        op = None if other_plans is None else np.ascontiguousarray(other_plans, dtype=np.float32)
+        plans = np.zeros((B, H, 2), dtype=np.float32)
+        loss = np.zeros(B, dtype=np.float32)
+        best = np.zeros(B, dtype=np.int32)
+        all_plans = np.zeros((B, K, H, 2), dtype=np.float32)
+        all_losses = np.zeros((B, K), dtype=np.float32)
+        st = self.lib.ocd_plan_batch_cpu(C.byref(desc), _fp(ws), _fp(w), per, _fp(op), _fp(plans), _fp(loss),
+                                         _ip(best), _fp(all_plans), _fp(all_losses), B, n_threads)
+        if st != 0:
+            raise RuntimeError(f"ocd_plan_batch_cpu -> {st}")
+        return dict(plans=plans, best_loss=loss, best_init=best, all_plans=all_plans, all_losses=all_losses)
+
+    def rollout(self, desc, init_states, cand_weights, ep_begin=0, ep_end=None, want_traj=False, n_threads=0):
+        init = np.ascontiguousarray(init_states, dtype=np.float32).reshape(-1, 4)
+        N = init.shape[0]
+        if cand_weights is None:
+            w, P = None, 1
+        else:
+            w = np.ascontiguousarray(cand_weights, dtype=np.float32).reshape(-1, desc.n_features)
+            P = w.shape[0]
+        E = P * N * desc.n_samples
+        if ep_end is None:
+            ep_end = E
+        n = ep_end - ep_begin
+        T, C_ = desc.episode_len, desc.n_cars
+        ret = np.zeros(n, dtype=np.float32)
+        traj = np.zeros((n, T + 1, C_, 4), dtype=np.float32) if want_traj else None
+        ctrl = np.zeros((n, T, 2), dtype=np.float32) if want_traj else None
+        st = self.lib.ocd_rollout_episodes_cpu(C.byref(desc), _fp(init), _fp(w), P, N, ep_begin, ep_end,
+                                               _fp(ret), _fp(traj), _fp(ctrl), n_threads)
+        if st != 0:
+            raise RuntimeError(f"ocd_rollout_episodes_cpu -> {st}")
+        return dict(returns=ret, traj=traj, ctrl=ctrl)
+
+    def reward_batch(self, desc, world_state, weights):
+        ws = np.ascontiguousarray(world_state, dtype=np.float32).reshape(-1, desc.n_cars, 4)
+        B = ws.shape[0]
+        w = np.ascontiguousarray(weights, dtype=np.float32)
+        feats = np.zeros((B, desc.n_features), dtype=np.float32)
+        rew = np.zeros(B, dtype=np.float32)
+        st = self.lib.ocd_reward_batch_cpu(C.byref(desc), _fp(ws), _fp(w), _fp(feats), _fp(rew), B)
+        if st != 0:
+            raise RuntimeError(f"ocd_reward_batch_cpu -> {st}")
+        return feats, rew
+
+
+_cache = {}
+
+
+def build(target: str = "all") -> None:
+    subprocess.run(["make", "-C", ORACLE_DIR, target], check=True, capture_output=True)
+
+
+def load(variant: str = "") -> Oracle:
+    """variant: '' (own exp/sin/cos, the parity oracle) or 'libm'."""
+    if variant in _cache:
+        return _cache[variant]
+    name = "libocd_oracle.so" if not variant else f"libocd_oracle_{variant}.so"
+    path = os.path.join(ORACLE_DIR, name)
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("ocd_oracle.c", "ocd_oracle.h", "ocd_refmath.h")]
+    srcs.append(os.path.join(ROOT, "include", "ocd.h"))
+    stale = (not os.path.exists(path)) or any(
+        os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(path) for s in srcs)
+    if stale:
+        try:
+            build("all" if not variant else variant)
+        except Exception:
+            if not os.path.exists(path):
+                raise
+    _cache[variant] = Oracle(path)
+    return _cache[variant]
