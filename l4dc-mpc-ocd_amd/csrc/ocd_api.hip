@@ -1,0 +1,319 @@
+// ocd_api.hip -- the C ABI of include/ocd.h over the gfx950 kernels.
+//
+// Host-side only: argument validation, kernel-argument packing, launches on
+// the caller's stream, error reporting.  No CPU implementation of the planner
+// lives here (or anywhere in the product): without a HIP device every compute
+// entry point returns OCD_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/ocd.h"
+#include "ocd_kernels.h"
+
+struct ocd_scenario {
+    ocd_scenario_desc desc;
+    int32_t K;
+    int32_t D;
+};
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int32_t fail(int32_t status, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return status;
+}
+
+int32_t hip_fail(hipError_t e, const char *what)
+{
+    return fail(OCD_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+int32_t validate(const ocd_scenario_desc *d)
+{
+    if (!d) return fail(OCD_ERR_INVALID_ARG, "descriptor is NULL");
+    if (d->abi_version != OCD_ABI_VERSION)
+        return fail(OCD_ERR_INVALID_ARG, "descriptor abi_version %d != %d", d->abi_version, OCD_ABI_VERSION);
+    if (d->reward_kind != OCD_REWARD_LANE_FEATURES && d->reward_kind != OCD_REWARD_TARGET_SPEED)
+        return fail(OCD_ERR_INVALID_ARG, "unknown reward_kind %d", d->reward_kind);
+    if (d->n_cars < 1 || d->n_cars > OCD_MAX_CARS) return fail(OCD_ERR_INVALID_ARG, "n_cars %d out of [1,%d]", d->n_cars, OCD_MAX_CARS);
+    if (d->n_lanes < 0 || d->n_lanes > OCD_MAX_LANES) return fail(OCD_ERR_INVALID_ARG, "n_lanes %d out of [0,%d]", d->n_lanes, OCD_MAX_LANES);
+    if (d->reward_kind == OCD_REWARD_LANE_FEATURES && (d->n_lanes < 1 || d->n_cars < 2))
+        return fail(OCD_ERR_INVALID_ARG, "lane-feature reward needs >=1 lane and >=1 scripted car");
+    if (d->horizon < 1 || d->horizon > OCD_MAX_HORIZON) return fail(OCD_ERR_INVALID_ARG, "horizon %d out of [1,%d]", d->horizon, OCD_MAX_HORIZON);
+    if (d->n_iter < 0) return fail(OCD_ERR_INVALID_ARG, "n_iter %d < 0", d->n_iter);
+    if (d->episode_len < 0) return fail(OCD_ERR_INVALID_ARG, "episode_len %d < 0", d->episode_len);
+    if (d->n_samples < 1 || d->n_samples > OCD_MAX_SAMPLES) return fail(OCD_ERR_INVALID_ARG, "n_samples %d out of [1,%d]", d->n_samples, OCD_MAX_SAMPLES);
+    for (int j = 0; j < d->n_cars - 1; ++j)
+        if (d->other_plan_len[j] < 0 || d->other_plan_len[j] > OCD_MAX_PLAN)
+            return fail(OCD_ERR_INVALID_ARG, "other_plan_len[%d] = %d out of [0,%d]", j, d->other_plan_len[j], OCD_MAX_PLAN);
+    if (d->teleport_step > 0)
+        for (int s = 0; s < d->n_samples; ++s)
+            if (d->teleport_car[s] >= d->n_cars)
+                return fail(OCD_ERR_INVALID_ARG, "teleport_car[%d] = %d >= n_cars", s, d->teleport_car[s]);
+    if (!(d->dt > 0.0f)) return fail(OCD_ERR_INVALID_ARG, "dt must be > 0");
+    return OCD_OK;
+}
+
+int32_t need_device()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(OCD_ERR_NO_DEVICE, "no HIP device visible (the planner has no CPU fallback)");
+    }
+    return OCD_OK;
+}
+
+void base_params(const ocd_scenario *scn, ocd::KernelParams &p)
+{
+    std::memset(&p, 0, sizeof(p));
+    p.d = scn->desc;
+    p.K = scn->K;
+    p.S = scn->desc.n_samples;
+}
+
+int32_t launch(const ocd_scenario *scn, const ocd::KernelParams &p, void *hip_stream)
+{
+    bool supported = false;
+    hipError_t e = ocd::launch_mpc_dispatch(scn->desc.horizon, scn->desc.n_cars - 1, p, (hipStream_t)hip_stream, &supported);
+    if (!supported)
+        return fail(OCD_ERR_UNSUPPORTED, "no compiled kernel for horizon %d with %d scripted cars (see OCD_KERNEL_TABLE)",
+                    scn->desc.horizon, scn->desc.n_cars - 1);
+    if (e != hipSuccess) return hip_fail(e, "mpc_kernel launch");
+    return OCD_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int32_t ocd_abi_version(void) { return OCD_ABI_VERSION; }
+
+int32_t ocd_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(OCD_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    return n;
+}
+
+const char *ocd_last_error(void) { return g_err; }
+
+int32_t ocd_scenario_create(const ocd_scenario_desc *desc, ocd_scenario **out)
+{
+    if (!out) return fail(OCD_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    int32_t st = validate(desc);
+    if (st != OCD_OK) return st;
+    ocd_scenario *s = new (std::nothrow) ocd_scenario;
+    if (!s) return fail(OCD_ERR_INVALID_ARG, "out of memory");
+    s->desc = *desc;
+    s->K = desc->extra_inits ? 6 : 3;
+    s->D = desc->n_lanes + 4;
+    *out = s;
+    return OCD_OK;
+}
+
+void ocd_scenario_destroy(ocd_scenario *scn) { delete scn; }
+
+int32_t ocd_plan_batch(const ocd_scenario *scn, const float *world_state,
+                       const float *weights, int32_t weights_per_problem, const float *other_plans,
+                       float *plans_out, float *best_loss_out, int32_t *best_init_out,
+                       float *all_plans_out, float *all_losses_out, int64_t B, void *hip_stream)
+{
+    if (!scn) return fail(OCD_ERR_INVALID_ARG, "scenario is NULL");
+    if (B < 0) return fail(OCD_ERR_INVALID_ARG, "B = %lld < 0", (long long)B);
+    if (B == 0) return OCD_OK;
+    if (!world_state || !plans_out) return fail(OCD_ERR_INVALID_ARG, "world_state / plans_out is NULL");
+    if (scn->desc.reward_kind == OCD_REWARD_LANE_FEATURES && !weights)
+        return fail(OCD_ERR_INVALID_ARG, "weights is NULL for a lane-feature reward");
+    int32_t st = need_device();
+    if (st != OCD_OK) return st;
+    ocd::KernelParams p;
+    base_params(scn, p);
+    p.mode = ocd::OCD_MODE_PLAN;
+    p.ego_states = world_state;
+    p.weights = weights;
+    p.weights_per_problem = weights_per_problem;
+    p.other_plans = other_plans;
+    p.plans_out = plans_out;
+    p.best_loss_out = best_loss_out;
+    p.best_init_out = best_init_out;
+    p.all_plans_out = all_plans_out;
+    p.all_losses_out = all_losses_out;
+    p.n_problems = B;
+    return launch(scn, p, hip_stream);
+}
+
+static int32_t rollout_params(const ocd_scenario *scn, const float *init_states, const float *cand_weights,
+                              int64_t P, int64_t N, int64_t ep_begin, int64_t ep_end,
+                              float *returns_out, float *traj_out, float *ctrl_out,
+                              const float *other_plans_dev, ocd::KernelParams &p)
+{
+    if (!scn) return fail(OCD_ERR_INVALID_ARG, "scenario is NULL");
+    if (P < 1 || N < 1) return fail(OCD_ERR_INVALID_ARG, "P = %lld, N = %lld must be >= 1", (long long)P, (long long)N);
+    const int64_t E = P * N * scn->desc.n_samples;
+    if (ep_begin < 0 || ep_end < ep_begin || ep_end > E)
+        return fail(OCD_ERR_INVALID_ARG, "episode range [%lld, %lld) outside [0, %lld)", (long long)ep_begin, (long long)ep_end, (long long)E);
+    if (!init_states || !returns_out) return fail(OCD_ERR_INVALID_ARG, "init_states / returns_out is NULL");
+    if (scn->desc.reward_kind == OCD_REWARD_LANE_FEATURES && !cand_weights)
+        return fail(OCD_ERR_INVALID_ARG, "cand_weights is NULL for a lane-feature reward");
+    base_params(scn, p);
+    p.mode = ocd::OCD_MODE_ROLLOUT;
+    p.ego_states = init_states;
+    p.weights = cand_weights;
+    p.other_plans = other_plans_dev;
+    p.returns_out = returns_out;
+    p.traj_out = traj_out;
+    p.ctrl_out = ctrl_out;
+    p.n_problems = ep_end - ep_begin;
+    p.ep_begin = ep_begin;
+    p.N = N;
+    return OCD_OK;
+}
+
+} // extern "C"
+
+// The planner's fixed view of the scripted cars' plans (planner_car.py:58-80:
+// plan[j] from index 0, then default_control) is a scenario constant; rollouts
+// read it from a small device buffer cached per (scenario handle, device).
+namespace {
+
+struct PlanCache {
+    const ocd_scenario *scn = nullptr;
+    int device = -1;
+    float *dev = nullptr;
+};
+thread_local PlanCache g_plan_cache;
+
+int32_t scripted_plans_device(const ocd_scenario *scn, hipStream_t st, const float **out)
+{
+    *out = nullptr;
+    const ocd_scenario_desc &d = scn->desc;
+    if (!d.check_plans || d.n_cars < 2) return OCD_OK;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return hip_fail(e, "hipGetDevice");
+    PlanCache &c = g_plan_cache;
+    if (c.scn == scn && c.device == dev && c.dev) { *out = c.dev; return OCD_OK; }
+    if (c.dev) { (void)hipFree(c.dev); c.dev = nullptr; }
+    const int H = d.horizon, NO = d.n_cars - 1;
+    float host[OCD_MAX_OTHERS * OCD_MAX_HORIZON * 2];
+    for (int j = 0; j < NO; ++j)
+        for (int t = 0; t < H; ++t) {
+            const float *src = (t < d.other_plan_len[j]) ? d.other_plan[j][t] : d.other_default[j];
+            host[(j * H + t) * 2] = src[0];
+            host[(j * H + t) * 2 + 1] = src[1];
+        }
+    const size_t bytes = sizeof(float) * NO * H * 2;
+    e = hipMalloc(&c.dev, bytes);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(scripted plans)");
+    e = hipMemcpyAsync(c.dev, host, bytes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);   // host[] is a stack buffer
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpy(scripted plans)");
+    c.scn = scn; c.device = dev;
+    *out = c.dev;
+    return OCD_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int32_t ocd_rollout_episodes(const ocd_scenario *scn, const float *init_states, const float *cand_weights,
+                             int64_t P, int64_t N, int64_t ep_begin, int64_t ep_end,
+                             float *returns_out, float *traj_out, float *ctrl_out, void *hip_stream)
+{
+    if (!scn) return fail(OCD_ERR_INVALID_ARG, "scenario is NULL");
+    if (ep_begin == ep_end && ep_begin >= 0) return OCD_OK;
+    int32_t st = need_device();
+    if (st != OCD_OK) return st;
+    const float *plans = nullptr;
+    st = scripted_plans_device(scn, (hipStream_t)hip_stream, &plans);
+    if (st != OCD_OK) return st;
+    ocd::KernelParams p;
+    st = rollout_params(scn, init_states, cand_weights, P, N, ep_begin, ep_end, returns_out, traj_out, ctrl_out, plans, p);
+    if (st != OCD_OK) return st;
+    return launch(scn, p, hip_stream);
+}
+
+int32_t ocd_reward_batch(const ocd_scenario *scn, const float *world_state, const float *weights,
+                         float *feats_out, float *reward_out, int64_t B, void *hip_stream)
+{
+    if (!scn) return fail(OCD_ERR_INVALID_ARG, "scenario is NULL");
+    if (B < 0) return fail(OCD_ERR_INVALID_ARG, "B < 0");
+    if (B == 0) return OCD_OK;
+    if (!world_state) return fail(OCD_ERR_INVALID_ARG, "world_state is NULL");
+    if (scn->desc.reward_kind == OCD_REWARD_LANE_FEATURES && !weights)
+        return fail(OCD_ERR_INVALID_ARG, "weights is NULL");
+    int32_t st = need_device();
+    if (st != OCD_OK) return st;
+    ocd::KernelParams p;
+    base_params(scn, p);
+    p.ego_states = world_state;
+    p.weights = weights;
+    p.n_problems = B;
+    bool supported = false;
+    hipError_t e = ocd::launch_reward(scn->desc.n_cars - 1, p, feats_out, reward_out, (hipStream_t)hip_stream, &supported);
+    if (!supported) return fail(OCD_ERR_UNSUPPORTED, "reward kernel: %d scripted cars", scn->desc.n_cars - 1);
+    if (e != hipSuccess) return hip_fail(e, "reward_kernel launch");
+    return OCD_OK;
+}
+
+int32_t ocd_debug_math(const float *in, float *exp_out, float *sin_out, float *cos_out, int64_t n, void *hip_stream)
+{
+    if (n < 0 || (n > 0 && !in)) return fail(OCD_ERR_INVALID_ARG, "bad arguments");
+    if (n == 0) return OCD_OK;
+    int32_t st = need_device();
+    if (st != OCD_OK) return st;
+    hipError_t e = ocd::launch_math(in, exp_out, sin_out, cos_out, n, (hipStream_t)hip_stream);
+    if (e != hipSuccess) return hip_fail(e, "math_kernel launch");
+    return OCD_OK;
+}
+
+int32_t ocd_time_rollout(const ocd_scenario *scn, const float *init_states, const float *cand_weights,
+                         int64_t P, int64_t N, int64_t ep_begin, int64_t ep_end,
+                         float *returns_out, int32_t reps, float *ms_out, void *hip_stream)
+{
+    if (!ms_out || reps < 1) return fail(OCD_ERR_INVALID_ARG, "ms_out is NULL or reps < 1");
+    if (!scn) return fail(OCD_ERR_INVALID_ARG, "scenario is NULL");
+    int32_t st = need_device();
+    if (st != OCD_OK) return st;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    const float *plans = nullptr;
+    st = scripted_plans_device(scn, stream, &plans);
+    if (st != OCD_OK) return st;
+    ocd::KernelParams p;
+    st = rollout_params(scn, init_states, cand_weights, P, N, ep_begin, ep_end, returns_out, nullptr, nullptr, plans, p);
+    if (st != OCD_OK) return st;
+    hipEvent_t e0, e1;
+    hipError_t e = hipEventCreate(&e0);
+    if (e != hipSuccess) return hip_fail(e, "hipEventCreate");
+    e = hipEventCreate(&e1);
+    if (e != hipSuccess) { (void)hipEventDestroy(e0); return hip_fail(e, "hipEventCreate"); }
+    (void)hipEventRecord(e0, stream);
+    for (int i = 0; i < reps && st == OCD_OK; ++i) st = launch(scn, p, hip_stream);
+    (void)hipEventRecord(e1, stream);
+    e = hipEventSynchronize(e1);
+    float ms = 0.0f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (st != OCD_OK) return st;
+    if (e != hipSuccess) return hip_fail(e, "event timing");
+    *ms_out = ms / (float)reps;
+    return OCD_OK;
+}
+
+} // extern "C"

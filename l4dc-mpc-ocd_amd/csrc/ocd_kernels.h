@@ -1,0 +1,49 @@
+// ocd_kernels.h -- host/device shared declarations of the planner kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ocd.h"
+
+namespace ocd {
+
+enum { OCD_MODE_ROLLOUT = 0, OCD_MODE_PLAN = 1 };
+
+// Kernel argument block (passed by value: lives in the kernarg segment, read
+// through scalar loads, so scenario constants cost no vector registers).
+struct KernelParams {
+    ocd_scenario_desc d;
+    const float *ego_states;   // ROLLOUT: init_states [N,4];  PLAN: world_state [B,C,4]
+    const float *weights;      // ROLLOUT: [P,D];  PLAN: [B,D] or [D]
+    const float *other_plans;  // [C-1,H,2] or nullptr (constant-velocity model)
+    float *returns_out;        // ROLLOUT [n]
+    float *traj_out;           // ROLLOUT [n,T+1,C,4] or nullptr
+    float *ctrl_out;           // ROLLOUT [n,T,2] or nullptr
+    float *plans_out;          // PLAN [B,H,2]
+    float *best_loss_out;      // PLAN [B] or nullptr
+    int32_t *best_init_out;    // PLAN [B] or nullptr
+    float *all_plans_out;      // PLAN [B,K,H,2] or nullptr
+    float *all_losses_out;     // PLAN [B,K] or nullptr
+    long long n_problems;      // trajectories handled by this launch
+    long long ep_begin;        // ROLLOUT: flat index of the first episode
+    long long N;               // ROLLOUT: number of init states
+    int32_t S;                 // ROLLOUT: samples per (candidate, init)
+    int32_t mode;
+    int32_t weights_per_problem;
+    int32_t K;                 // control initialisations = wavefronts per workgroup
+};
+
+// (horizon, scripted cars) pairs with a compiled kernel.  Horizons 5/6: the
+// reference's own settings; 10/15/25: BASELINE.json configs 2-5; the rest for
+// tests and sweeps.  Anything else returns OCD_ERR_UNSUPPORTED.
+#define OCD_KERNEL_TABLE(X)                                                        \
+    X(3, 0) X(5, 0)                                                                \
+    X(3, 1) X(4, 1) X(5, 1) X(6, 1) X(8, 1) X(10, 1) X(12, 1) X(15, 1) X(16, 1)    \
+    X(20, 1) X(25, 1) X(32, 1)                                                     \
+    X(3, 2) X(5, 2) X(6, 2) X(8, 2) X(10, 2) X(15, 2) X(20, 2) X(25, 2) X(5, 3)
+
+hipError_t launch_mpc_dispatch(int H, int NO, const KernelParams &p, hipStream_t st, bool *supported);
+hipError_t launch_reward(int NO, const KernelParams &p, float *feats, float *rew, hipStream_t st, bool *supported);
+hipError_t launch_math(const float *in, float *e, float *s, float *c, long long n, hipStream_t st);
+
+} // namespace ocd

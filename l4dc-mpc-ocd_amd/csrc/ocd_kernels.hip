@@ -1,0 +1,760 @@
+// ocd_kernels.hip -- hand-written gfx950 kernels of the batched MPC planner.
+//
+// What runs here (reference file:line, relative to the reference tree):
+//   NaivePlanner.generate_plan / mpc_reward   interact_drive/planner/naive_planner.py:33-77,81-164
+//   car_dynamics_step                         interact_drive/simulation_utils.py:9-21
+//   ThreeLaneTestCar.features                 experiments/merging.py:32-83
+//   _f / smooth_threshold / smooth_bump       interact_drive/math_utils.py:7-31,59-97,135-180
+//   LinearRewardCar.reward_fn                 interact_drive/car/linear_reward_car.py:49-55
+//   CarWorld.step, Car.step, FixedPlanCar     interact_drive/world.py:79-109, car/car.py:76-87,
+//                                             car/fixed_plan_car.py:25-39
+//   ReplanningCarWorld                        experiments/replanning_world.py:24-36
+//   MPC_ORD.eval_weights_for_init             interact_drive/reward_design/mpc_ord.py:67-106
+//
+// Mapping.  A workgroup is K wavefronts, K = number of
+// control initialisations (3, or 6 with extra_inits); wavefront k optimises
+// initialisation k.  Inside a wavefront the 64 lanes are cut into SEGS = 64/H
+// segments of H lanes; segment s is one trajectory (one (candidate, init,
+// sample) episode, or one world state in plan mode) and lane t of the segment
+// owns horizon step t: its control u_t, the state before and after step t, the
+// reward features at the post-step state and their adjoint.
+//
+// Per SGD iteration the only sequential work is four short recurrences
+// (v/heading forward, x/y forward, x/y adjoint, v/heading adjoint); every lane
+// of a segment runs them redundantly on values the segment exchanged through
+// LDS (one ds_write_b32 per lane, ds_read_b128 broadcasts back), keeping its
+// own prefix by predication.  Everything else -- sincos, the feature
+// exponentials and IEEE divisions, the per-step Jacobian products -- is
+// lane-parallel.  The K wavefronts meet once per control step (one
+// __syncthreads) to pick the best initialisation, then all of them apply the
+// chosen control to the real dynamics.
+//
+// Numerics: IEEE binary32, -ffp-contract=off, operation order = the
+// arithmetic contract of DESIGN.md section 3; exp/sin/cos from ocd_devmath.h.
+// No MFMA: there is no dense contraction on this path.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ocd.h"
+#include "ocd_devmath.h"
+#include "ocd_kernels.h"
+
+namespace ocd {
+
+// ---------------------------------------------------------------- primitives
+__device__ __forceinline__ float min_tf(float a, float b) { return (a <= b) ? a : b; }
+__device__ __forceinline__ float max_tf(float a, float b) { return (a >= b) ? a : b; }
+
+// _f (math_utils.py:28-31)
+struct FTape { bool pos; float m, e, u; };
+
+__device__ __forceinline__ float f_fwd(float t, float shape, FTape &tp)
+{
+    const bool pos = t > 0.0f;
+    const float tc = pos ? t : (0.0f + 0.01f);
+    const float u = shape * tc;
+    const float m = -1.0f / u;
+    const float e = exp_(m);
+    tp.pos = pos; tp.m = m; tp.e = e; tp.u = u;
+    return pos ? e : 0.0f;
+}
+
+__device__ __forceinline__ float f_bwd(float g, float shape, const FTape &tp, float k /* (-m)/u */)
+{
+    const float g_e = tp.pos ? g : 0.0f;
+    const float g_m = g_e * tp.e;
+    const float g_u = g_m * k;
+    const float g_tc = g_u * shape;
+    return tp.pos ? g_tc : 0.0f;
+}
+
+// smooth_threshold (math_utils.py:87-95)
+struct ThrTape { FTape t1, t2; float den, S; };
+
+__device__ __forceinline__ float thr_fwd(float z, float lo, float width, float shape, ThrTape &tp)
+{
+    const float xd = z - lo;
+    const float F1 = f_fwd(xd, shape, tp.t1);
+    const float xd2 = width - xd;
+    const float F2 = f_fwd(xd2, shape, tp.t2);
+    const float den = F1 + F2;
+    const float S = F1 / den;
+    tp.den = den; tp.S = S;
+    return S;
+}
+
+__device__ __forceinline__ float thr_bwd(float g_S, float shape, const ThrTape &tp)
+{
+    const float g_F1a = g_S / tp.den;
+    const float g_den = g_S * ((-tp.S) / tp.den);
+    const float k1 = (-tp.t1.m) / tp.t1.u;      // shared by the two _f(x_diff) call sites
+    const float k2 = (-tp.t2.m) / tp.t2.u;
+    const float ga = f_bwd(g_F1a, shape, tp.t1, k1);
+    const float gb = f_bwd(g_den, shape, tp.t1, k1);
+    const float gc = f_bwd(g_den, shape, tp.t2, k2);
+    return (ga + gb) + (-gc);
+}
+
+// smooth_bump (math_utils.py:166-178); center/width precomputed per control step
+struct BumpTape { bool cond; float xc, q, m, e; };
+
+__device__ __forceinline__ float bump_fwd(float z, float center, float width, BumpTape &tp)
+{
+    const float zn = (z - center) / width;
+    const bool cond = (zn * zn) < 1.0f;
+    const float xc = cond ? zn : 0.0f;
+    const float q = 1.0f - xc * xc;
+    const float m = -1.0f / q;
+    const float arg = m + 1.0f;
+    const float e = exp_(arg);
+    tp.cond = cond; tp.xc = xc; tp.q = q; tp.m = m; tp.e = e;
+    return cond ? e : 0.0f;
+}
+
+__device__ __forceinline__ float bump_bwd(float g, float width, const BumpTape &tp)
+{
+    const float g_e = tp.cond ? g : 0.0f;
+    const float g_arg = g_e * tp.e;
+    const float g_q = g_arg * ((-tp.m) / tp.q);
+    const float g_xc2 = -g_q;
+    const float g_xc = (g_xc2 * 2.0f) * tp.xc;
+    const float g_zn = tp.cond ? g_xc : 0.0f;
+    return g_zn / width;
+}
+
+// car_dynamics_step (simulation_utils.py:9-21) on explicit cos/sin of the heading
+__device__ __forceinline__ void dyn_step(float x, float y, float v, float th, float c, float s,
+                                         float a, float w, float dt, float dt2, float f,
+                                         float &xn, float &yn, float &vn, float &thn)
+{
+    const float a_c = max_tf(min_tf(a, 4.0f), -8.0f);
+    const float w_c = max_tf(min_tf(w, 4.0f), -4.0f);
+    const float v2 = v * v;
+    const float fv2 = f * v2;
+    const float acc = a_c - fv2;
+    const float vdt = v * dt;
+    const float hA = 0.5f * acc;
+    const float hAdt2 = hA * dt2;
+    const float d = vdt + hAdt2;
+    xn = x + c * d;
+    yn = y + s * d;
+    vn = v + acc * dt;
+    thn = th + w_c * dt;
+}
+
+// bump centre / half-width of a scripted car at (ox, oy): smooth_bump(o - h, o + h)
+// (merging.py:72-73, math_utils.py:167-168)
+struct BumpGeom { float cx, wx, cy, wy; };
+
+__device__ __forceinline__ BumpGeom bump_geom(float ox, float oy, float hx, float hy)
+{
+    BumpGeom g;
+    const float sx = ox - hx, ex = ox + hx;
+    g.wx = (ex - sx) / 2.0f;
+    g.cx = (sx + ex) / 2.0f;
+    const float sy = oy - hy, ey = oy + hy;
+    g.wy = (ey - sy) / 2.0f;
+    g.cy = (sy + ey) / 2.0f;
+    return g;
+}
+
+struct Q4 { float qx, qy, qv, qth; };
+
+// reward of one world state and (GRAD) its gradient w.r.t. the ego state
+// (merging.py:44-83, linear_reward_car.py:49-55, targetSpeedRewardMaximizerCar.py:50-56)
+template <int NO, bool GRAD>
+__device__ __forceinline__ float reward_state(const ocd_scenario_desc &d, const float (&w)[OCD_MAX_FEATURES],
+                                              float x, float y, float v, float sn, float cn,
+                                              const BumpGeom (&bg)[NO > 0 ? NO : 1], Q4 &q,
+                                              float *feats /* nullptr or [D] global */)
+{
+    if (d.reward_kind == OCD_REWARD_TARGET_SPEED) {
+        const float dv = v - d.target_speed;
+        const float sq = dv * dv;
+        if (GRAD) { q.qx = 0.0f; q.qy = 0.0f; q.qth = 0.0f; q.qv = (-1.0f * 2.0f) * dv; }
+        return 0.0f - sq;
+    }
+    const int L = d.n_lanes;
+    float phi[OCD_MAX_FEATURES];
+
+    const float tgt = d.target_speed;
+    const float bound = 4.0f * (tgt * tgt);
+    const float vel = v * sn;
+    const float dv = vel - tgt;
+    const float sq = dv * dv;
+    const bool pass0 = sq <= bound;
+    phi[0] = min_tf(sq, bound);
+
+    float rl[OCD_MAX_LANES], pl[OCD_MAX_LANES];
+    float pmin = 0.0f;
+#pragma unroll
+    for (int l = 0; l < OCD_MAX_LANES; ++l) {
+        if (l < L) {
+            const float diff = x - d.lane_center[l];
+            rl[l] = diff * -1.0f;
+            const float d2 = rl[l] * rl[l];
+            pl[l] = d2 * 10.0f;
+            pmin = (l == 0) ? pl[0] : min_tf(pmin, pl[l]);
+        } else { rl[l] = 0.0f; pl[l] = 0.0f; }
+    }
+    int ntie_min = 0;
+#pragma unroll
+    for (int l = 0; l < OCD_MAX_LANES; ++l) if (l < L) ntie_min += (pl[l] == pmin) ? 1 : 0;
+
+    BumpTape bx[NO > 0 ? NO : 1], by[NO > 0 ? NO : 1];
+    float bxv[NO > 0 ? NO : 1], byv[NO > 0 ? NO : 1], col[NO > 0 ? NO : 1];
+    float pcol = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NO; ++j) {
+        bxv[j] = bump_fwd(x, bg[j].cx, bg[j].wx, bx[j]);
+        byv[j] = bump_fwd(y, bg[j].cy, bg[j].wy, by[j]);
+        col[j] = bxv[j] * byv[j];
+        pcol = (j == 0) ? col[0] : max_tf(pcol, col[j]);
+    }
+    int ntie_col = 0;
+#pragma unroll
+    for (int j = 0; j < NO; ++j) ntie_col += (col[j] == pcol) ? 1 : 0;
+
+    ThrTape tp_p, tp_m;
+    const float Sp = thr_fwd(x, d.fence_lo, d.fence_width, d.fence_shape, tp_p);
+    const float Sm = thr_fwd(-x, d.fence_lo, d.fence_width, d.fence_shape, tp_m);
+    const float Ssum = Sp + Sm;
+    const float ax = (x < 0.0f) ? -x : x;
+    const float pf = Ssum * ax;
+
+    // reduce_sum(weights * feats), left to right over [phi0, lanes..., min, collision, fences]
+    float r = w[0] * phi[0];
+#pragma unroll
+    for (int l = 0; l < OCD_MAX_LANES; ++l) if (l < L) r = r + w[1 + l] * pl[l];
+    // the feature index of min / collision / fences depends on L: select the weight registers
+    float w_min = 0.0f, w_col = 0.0f, w_f = 0.0f;
+#pragma unroll
+    for (int k = 1; k < OCD_MAX_FEATURES; ++k) {
+        w_min = (k == L + 1) ? w[k] : w_min;
+        w_col = (k == L + 2) ? w[k] : w_col;
+        w_f = (k == L + 3) ? w[k] : w_f;
+    }
+    r = r + w_min * pmin;
+    r = r + w_col * pcol;
+    r = r + w_f * pf;
+    if (feats) {
+        feats[0] = phi[0];
+#pragma unroll
+        for (int l = 0; l < OCD_MAX_LANES; ++l) if (l < L) feats[1 + l] = pl[l];
+        feats[L + 1] = pmin; feats[L + 2] = pcol; feats[L + 3] = pf;
+    }
+    if (!GRAD) return r;
+
+    const float g_sq = pass0 ? w[0] : 0.0f;
+    const float g_dv = (g_sq * 2.0f) * dv;
+    q.qv = g_dv * sn;
+    const float g_sn = g_dv * v;
+    q.qth = g_sn * cn;
+
+    float qx = 0.0f, qy = 0.0f;
+    const float min_share = w_min / (float)ntie_min;
+#pragma unroll
+    for (int l = 0; l < OCD_MAX_LANES; ++l) {
+        if (l < L) {
+            float g = w[1 + l];
+            g = (pl[l] == pmin) ? (g + min_share) : g;
+            const float g_d2 = g * 10.0f;
+            const float g_r = (g_d2 * 2.0f) * rl[l];
+            qx = qx + g_r * -1.0f;
+        }
+    }
+    if (NO > 0) {
+        const float col_share = w_col / (float)ntie_col;
+#pragma unroll
+        for (int j = 0; j < NO; ++j) {
+            const float share = (col[j] == pcol) ? col_share : 0.0f;
+            const float g_bx = share * byv[j];
+            const float g_by = share * bxv[j];
+            qx = qx + bump_bwd(g_bx, bg[j].wx, bx[j]);
+            qy = qy + bump_bwd(g_by, bg[j].wy, by[j]);
+        }
+    }
+    const float g_Ssum = w_f * ax;
+    const float g_ax = w_f * Ssum;
+    qx = qx + thr_bwd(g_Ssum, d.fence_shape, tp_p);
+    qx = qx + (-thr_bwd(g_Ssum, d.fence_shape, tp_m));
+    const float sgn = (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f);
+    qx = qx + g_ax * sgn;
+    q.qx = qx; q.qy = qy;
+    return r;
+}
+
+// ---------------------------------------------------------------- segment exchange through LDS
+// Each wavefront owns NARR arrays of SEGP floats; a lane writes its own slot,
+// then every lane of a segment reads the segment's H values back (broadcast
+// ds_read_b128).  Wave-synchronous: DS operations of one wavefront execute in
+// program order, so no s_barrier is needed; wave_barrier() only pins the
+// compiler's schedule.
+template <int H>
+struct Geo {
+    static constexpr int HP = (H + 3) & ~3;          // segment stride in LDS (16-byte aligned rows)
+    static constexpr int SEGS = 64 / H;              // trajectories per wavefront
+    static constexpr int SEGP = (SEGS + 1) * HP;     // +1: lanes past the last segment park here
+    static constexpr int NARR = 6;
+};
+
+template <int H>
+__device__ __forceinline__ void seg_load(const float *row, float (&out)[Geo<H>::HP])
+{
+#pragma unroll
+    for (int i = 0; i < Geo<H>::HP / 4; ++i) {
+        const float4 v = *reinterpret_cast<const float4 *>(row + 4 * i);
+        out[4 * i] = v.x; out[4 * i + 1] = v.y; out[4 * i + 2] = v.z; out[4 * i + 3] = v.w;
+    }
+}
+
+// ---------------------------------------------------------------- the kernel
+template <int H, int NO>
+__global__ void __launch_bounds__(64 * OCD_MAX_CTRL_INITS)
+mpc_kernel(const KernelParams p)
+{
+    using G = Geo<H>;
+    constexpr int HP = G::HP, SEGS = G::SEGS, SEGP = G::SEGP, NARR = G::NARR;
+    constexpr int NOA = NO > 0 ? NO : 1;
+    const ocd_scenario_desc &d = p.d;
+
+    extern __shared__ float4 lds_raw[];
+    float *lds = reinterpret_cast<float *>(lds_raw);
+    const int K = p.K;
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int seg = lane / H;                 // SEGS for the parked tail lanes
+    const int t = lane - seg * H;
+    float *xch = lds + (size_t)wave * NARR * SEGP;          // this wavefront's exchange arrays
+    float *sel = lds + (size_t)K * NARR * SEGP;             // [2][K][SEGS][4] selection records
+    const int slot = seg * HP + t;
+    const int rowb = seg * HP;
+
+    const long long prob_raw = (long long)blockIdx.x * SEGS + seg;
+    const bool live = (seg < SEGS) && (prob_raw < p.n_problems);
+    const long long prob = live ? prob_raw : (p.n_problems - 1);     // parked lanes shadow a real problem
+
+    const float dt = d.dt, dt2 = d.dt_sq, fr = d.ego_friction, lr = d.learning_rate;
+    const int D = d.n_lanes + 4;
+
+    // ---- problem inputs -------------------------------------------------
+    float ex, ey, ev, eth;                    // ego state
+    float ox[NOA], oy[NOA], ov[NOA], oth[NOA];
+    float w[OCD_MAX_FEATURES];
+    int sample = 0;
+    long long e_glob = 0;
+    if (p.mode == OCD_MODE_ROLLOUT) {
+        e_glob = p.ep_begin + prob;           // flat (p, n, s) index
+        const long long s_ = e_glob % p.S, n_ = (e_glob / p.S) % p.N, p_ = e_glob / ((long long)p.S * p.N);
+        sample = (int)s_;
+        const float *ini = p.ego_states + 4 * n_;
+        ex = ini[0]; ey = ini[1]; ev = ini[2]; eth = ini[3];
+#pragma unroll
+        for (int j = 0; j < NO; ++j) {
+            ox[j] = d.other_init[j][0]; oy[j] = d.other_init[j][1];
+            ov[j] = d.other_init[j][2]; oth[j] = d.other_init[j][3];
+        }
+#pragma unroll
+        for (int k = 0; k < OCD_MAX_FEATURES; ++k) w[k] = (p.weights && k < D) ? p.weights[p_ * D + k] : 0.0f;
+    } else {
+        const float *ws = p.ego_states + prob * (NO + 1) * 4;
+        ex = ws[0]; ey = ws[1]; ev = ws[2]; eth = ws[3];
+#pragma unroll
+        for (int j = 0; j < NO; ++j) {
+            ox[j] = ws[4 * (j + 1)]; oy[j] = ws[4 * (j + 1) + 1];
+            ov[j] = ws[4 * (j + 1) + 2]; oth[j] = ws[4 * (j + 1) + 3];
+        }
+        const float *wp = p.weights ? (p.weights + (p.weights_per_problem ? prob * D : 0)) : nullptr;
+#pragma unroll
+        for (int k = 0; k < OCD_MAX_FEATURES; ++k) w[k] = (wp && k < D) ? wp[k] : 0.0f;
+    }
+    float wd[OCD_MAX_FEATURES];               // designer weights (uniform)
+#pragma unroll
+    for (int k = 0; k < OCD_MAX_FEATURES; ++k) wd[k] = d.designer_weights[k];
+
+    const int T = (p.mode == OCD_MODE_ROLLOUT) ? d.episode_len : 1;
+    float G_ret = 0.0f;
+    const BumpGeom bg0 = {0.0f, 1.0f, 0.0f, 1.0f};
+
+    if (p.mode == OCD_MODE_ROLLOUT && p.traj_out && live && wave == 0 && t == 0) {
+        float *tr = p.traj_out + (size_t)prob * (T + 1) * (NO + 1) * 4;
+        tr[0] = ex; tr[1] = ey; tr[2] = ev; tr[3] = eth;
+#pragma unroll
+        for (int j = 0; j < NO; ++j) {
+            tr[4 * (j + 1)] = ox[j]; tr[4 * (j + 1) + 1] = oy[j]; tr[4 * (j + 1) + 2] = ov[j]; tr[4 * (j + 1) + 3] = oth[j];
+        }
+    }
+
+    for (int step = 0; step < T; ++step) {
+        if (p.mode == OCD_MODE_ROLLOUT) {
+            // ReplanningCarWorld.step: self.t += 1; teleport when self.t == critical_t
+            if (d.teleport_step > 0 && (step + 1) == d.teleport_step) {
+                const int car = d.teleport_car[sample];
+#pragma unroll
+                for (int j = 0; j < NO; ++j) {
+                    if (car == j + 1) {
+                        ox[j] = d.teleport_state[0]; oy[j] = d.teleport_state[1];
+                        ov[j] = d.teleport_state[2]; oth[j] = d.teleport_state[3];
+                    }
+                }
+            }
+            // designer reward of the pre-step state (mpc_ord.py:99)
+            BumpGeom bgd[NOA];
+            bgd[0] = bg0;
+#pragma unroll
+            for (int j = 0; j < NO; ++j) bgd[j] = bump_geom(ox[j], oy[j], d.bump_half_x, d.bump_half_y);
+            float s_, c_;
+            sincos_(eth, s_, c_);
+            Q4 qd;
+            const float r = reward_state<NO, false>(d, wd, ex, ey, ev, s_, c_, bgd, qd, nullptr);
+            G_ret = G_ret + r;
+        }
+
+        // ---- planner's model of the scripted cars over the horizon (naive_planner.py:51-66) ----
+        BumpGeom bg[NOA];
+        bg[0] = bg0;
+#pragma unroll
+        for (int j = 0; j < NO; ++j) {
+            float px = ox[j], py = oy[j], pv = ov[j], pth = oth[j];
+            float cap_x = px, cap_y = py;
+            if (p.other_plans) {
+                for (int tt = 0; tt < H; ++tt) {
+                    float s_, c_;
+                    sincos_(pth, s_, c_);
+                    const float acc = p.other_plans[(j * H + tt) * 2], angv = p.other_plans[(j * H + tt) * 2 + 1];
+                    const float dist = pv * dt + (0.5f * acc) * dt2;
+                    px = px + c_ * dist;
+                    py = py + s_ * dist;
+                    pv = pv + acc * dt;
+                    pth = pth + angv * dt;
+                    cap_x = (tt == t) ? px : cap_x;
+                    cap_y = (tt == t) ? py : cap_y;
+                }
+            } else {
+                float s_, c_;
+                sincos_(pth, s_, c_);
+                const float incx = (c_ * pv) * dt, incy = (s_ * pv) * dt;
+                for (int tt = 0; tt < H; ++tt) {
+                    px = px + incx;
+                    py = py + incy;
+                    cap_x = (tt == t) ? px : cap_x;
+                    cap_y = (tt == t) ? py : cap_y;
+                }
+            }
+            bg[j] = bump_geom(cap_x, cap_y, d.bump_half_x, d.bump_half_y);
+        }
+
+        // ---- this wavefront's control initialisation (naive_planner.py:107-116) ----
+        float s0, c0;
+        sincos_(eth, s0, c0);
+        const float a_coast = fr * (ev * ev);
+        const int k3 = wave % 3;
+        float ua = (wave >= 3) ? a_coast : 0.0f;
+        float uw = (k3 == 0) ? 0.0f : ((k3 == 1) ? -0.65f : 0.65f);
+
+        float loss = 0.0f;
+        const int n_iter = d.n_iter;
+        for (int it = 0; it <= n_iter; ++it) {
+            // ===== forward =====
+            const float a1 = min_tf(ua, 4.0f);
+            const float a_c = max_tf(a1, -8.0f);
+            const float w1 = min_tf(uw, 4.0f);
+            const float w_c = max_tf(w1, -4.0f);
+            const bool pass_a = (ua <= 4.0f) && (a1 >= -8.0f);
+            const bool pass_w = (uw <= 4.0f) && (w1 >= -4.0f);
+            const float wdt = w_c * dt;
+
+            xch[0 * SEGP + slot] = a_c;
+            xch[1 * SEGP + slot] = wdt;
+            __builtin_amdgcn_wave_barrier();
+            float v = ev, th = eth;
+            {
+                float A[HP], W[HP];
+                seg_load<H>(xch + 0 * SEGP + rowb, A);
+                seg_load<H>(xch + 1 * SEGP + rowb, W);
+#pragma unroll
+                for (int j = 0; j < H - 1; ++j) {
+                    const float vn_ = v + (A[j] - fr * (v * v)) * dt;
+                    const float thn_ = th + W[j];
+                    v = (j < t) ? vn_ : v;
+                    th = (j < t) ? thn_ : th;
+                }
+            }
+            // own step t: (v, th) is the state before it
+            const float v2 = v * v;
+            const float fv2 = fr * v2;
+            const float acc = a_c - fv2;
+            const float vdt = v * dt;
+            const float hA = 0.5f * acc;
+            const float hAdt2 = hA * dt2;
+            const float dd = vdt + hAdt2;
+            const float vn = v + acc * dt;
+            const float thn = th + wdt;
+            float sn, cn;
+            sincos_(thn, sn, cn);
+            float s_pre = __shfl_up(sn, 1);
+            float c_pre = __shfl_up(cn, 1);
+            s_pre = (t == 0) ? s0 : s_pre;
+            c_pre = (t == 0) ? c0 : c_pre;
+            const float cd = c_pre * dd;
+            const float sd = s_pre * dd;
+            __builtin_amdgcn_wave_barrier();
+            xch[2 * SEGP + slot] = cd;
+            xch[3 * SEGP + slot] = sd;
+            __builtin_amdgcn_wave_barrier();
+            float x = ex, y = ey;
+            {
+                float CD[HP], SD[HP];
+                seg_load<H>(xch + 2 * SEGP + rowb, CD);
+                seg_load<H>(xch + 3 * SEGP + rowb, SD);
+#pragma unroll
+                for (int j = 0; j < H - 1; ++j) {
+                    const float xn_ = x + CD[j];
+                    const float yn_ = y + SD[j];
+                    x = (j < t) ? xn_ : x;
+                    y = (j < t) ? yn_ : y;
+                }
+            }
+            const float xn = x + cd;
+            const float yn = y + sd;
+
+            Q4 q;
+            if (it == n_iter) {
+                // ===== last pass: objective only (naive_planner.py:154) =====
+                const float r = reward_state<NO, false>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr);
+                __builtin_amdgcn_wave_barrier();
+                xch[4 * SEGP + slot] = r;
+                __builtin_amdgcn_wave_barrier();
+                float R[HP];
+                seg_load<H>(xch + 4 * SEGP + rowb, R);
+                float Rsum = 0.0f;
+#pragma unroll
+                for (int j = 0; j < H; ++j) Rsum = Rsum + R[j];
+                loss = -Rsum;
+                break;
+            }
+            reward_state<NO, true>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr);
+
+            // ===== backward =====
+            __builtin_amdgcn_wave_barrier();
+            xch[0 * SEGP + slot] = q.qx;
+            xch[1 * SEGP + slot] = q.qy;
+            __builtin_amdgcn_wave_barrier();
+            float Lx = 0.0f, Ly = 0.0f;
+            {
+                float QX[HP], QY[HP];
+                seg_load<H>(xch + 0 * SEGP + rowb, QX);
+                seg_load<H>(xch + 1 * SEGP + rowb, QY);
+#pragma unroll
+                for (int j = H - 1; j >= 1; --j) {
+                    const float ax_ = QX[j] + Lx;
+                    const float ay_ = QY[j] + Ly;
+                    Lx = (j > t) ? ax_ : Lx;
+                    Ly = (j > t) ? ay_ : Ly;
+                }
+            }
+            const float Ax = q.qx + Lx;
+            const float Ay = q.qy + Ly;
+            const float g_c = Ax * dd;
+            const float g_s = Ay * dd;
+            const float g_d = Ax * c_pre + Ay * s_pre;
+            const float tau = (-g_c) * s_pre + g_s * c_pre;
+            const float gv1 = g_d * dt;
+            const float gA1 = (g_d * dt2) * 0.5f;
+            __builtin_amdgcn_wave_barrier();
+            xch[0 * SEGP + slot] = q.qv;
+            xch[1 * SEGP + slot] = gA1;
+            xch[2 * SEGP + slot] = gv1;
+            xch[3 * SEGP + slot] = v;
+            xch[4 * SEGP + slot] = q.qth;
+            xch[5 * SEGP + slot] = tau;
+            __builtin_amdgcn_wave_barrier();
+            float Lv = 0.0f, Lth = 0.0f;
+            {
+                float QV[HP], GA1[HP], GV1[HP], VV[HP], QTH[HP], TAU[HP];
+                seg_load<H>(xch + 0 * SEGP + rowb, QV);
+                seg_load<H>(xch + 1 * SEGP + rowb, GA1);
+                seg_load<H>(xch + 2 * SEGP + rowb, GV1);
+                seg_load<H>(xch + 3 * SEGP + rowb, VV);
+                seg_load<H>(xch + 4 * SEGP + rowb, QTH);
+                seg_load<H>(xch + 5 * SEGP + rowb, TAU);
+#pragma unroll
+                for (int j = H - 1; j >= 1; --j) {
+                    const float Av_ = QV[j] + Lv;
+                    const float gA_ = GA1[j] + Av_ * dt;
+                    const float gv2_ = (-gA_) * fr;
+                    const float gv3_ = (gv2_ * 2.0f) * VV[j];
+                    const float Lv_ = (GV1[j] + Av_) + gv3_;
+                    const float Ath_ = QTH[j] + Lth;
+                    const float Lth_ = Ath_ + TAU[j];
+                    Lv = (j > t) ? Lv_ : Lv;
+                    Lth = (j > t) ? Lth_ : Lth;
+                }
+            }
+            const float Av = q.qv + Lv;
+            const float gA = gA1 + Av * dt;
+            const float Ath = q.qth + Lth;
+            const float grad_a = pass_a ? gA : 0.0f;
+            const float grad_w = pass_w ? (Ath * dt) : 0.0f;
+            // SGD on loss = -R:  u <- u + lr * dR/du
+            ua = ua + lr * grad_a;
+            uw = uw + lr * grad_w;
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        // ---- per-initialisation outputs (plan mode, parity tests) ----
+        if (p.mode == OCD_MODE_PLAN && live) {
+            if (p.all_plans_out) {
+                float *o = p.all_plans_out + (((size_t)prob * K + wave) * H + t) * 2;
+                o[0] = ua; o[1] = uw;
+            }
+            if (p.all_losses_out && t == 0) p.all_losses_out[(size_t)prob * K + wave] = loss;
+        }
+
+        // ---- first-index argmin over the K initialisations (naive_planner.py:161-162) ----
+        float *selb = sel + (size_t)(step & 1) * K * (SEGS + 1) * 4;
+        if (t == 0) {
+            float *rec = selb + ((size_t)wave * (SEGS + 1) + seg) * 4;
+            rec[0] = loss; rec[1] = ua; rec[2] = uw;
+        }
+        __syncthreads();
+        int best = 0;
+        float bl = selb[((size_t)0 * (SEGS + 1) + seg) * 4];
+        for (int k = 1; k < K; ++k) {
+            const float lk = selb[((size_t)k * (SEGS + 1) + seg) * 4];
+            if (lk < bl) { bl = lk; best = k; }
+        }
+        const float *brec = selb + ((size_t)best * (SEGS + 1) + seg) * 4;
+        const float ca = brec[1], cw = brec[2];
+
+        if (p.mode == OCD_MODE_PLAN) {
+            if (live && wave == best) {
+                float *o = p.plans_out + ((size_t)prob * H + t) * 2;
+                o[0] = ua; o[1] = uw;
+                if (t == 0) {
+                    if (p.best_loss_out) p.best_loss_out[prob] = bl;
+                    if (p.best_init_out) p.best_init_out[prob] = best;
+                }
+            }
+        } else {
+            // ---- every car steps through the real dynamics (world.py:106-107) ----
+            float nx, ny, nv, nth;
+            dyn_step(ex, ey, ev, eth, c0, s0, ca, cw, dt, dt2, fr, nx, ny, nv, nth);
+            ex = nx; ey = ny; ev = nv; eth = nth;
+#pragma unroll
+            for (int j = 0; j < NO; ++j) {
+                const bool in_plan = step < d.other_plan_len[j];
+                const float u0 = in_plan ? d.other_plan[j][step & (OCD_MAX_PLAN - 1)][0] : d.other_default[j][0];
+                const float u1 = in_plan ? d.other_plan[j][step & (OCD_MAX_PLAN - 1)][1] : d.other_default[j][1];
+                float s_, c_;
+                sincos_(oth[j], s_, c_);
+                dyn_step(ox[j], oy[j], ov[j], oth[j], c_, s_, u0, u1, dt, dt2, d.other_friction[j], nx, ny, nv, nth);
+                ox[j] = nx; oy[j] = ny; ov[j] = nv; oth[j] = nth;
+            }
+            if (live && wave == 0 && t == 0) {
+                if (p.ctrl_out) {
+                    float *o = p.ctrl_out + ((size_t)prob * T + step) * 2;
+                    o[0] = ca; o[1] = cw;
+                }
+                if (p.traj_out) {
+                    float *tr = p.traj_out + ((size_t)prob * (T + 1) + step + 1) * (NO + 1) * 4;
+                    tr[0] = ex; tr[1] = ey; tr[2] = ev; tr[3] = eth;
+#pragma unroll
+                    for (int j = 0; j < NO; ++j) {
+                        tr[4 * (j + 1)] = ox[j]; tr[4 * (j + 1) + 1] = oy[j];
+                        tr[4 * (j + 1) + 2] = ov[j]; tr[4 * (j + 1) + 3] = oth[j];
+                    }
+                }
+            }
+        }
+    }
+    if (p.mode == OCD_MODE_ROLLOUT && live && wave == 0 && t == 0) p.returns_out[prob] = G_ret;
+}
+
+// ---------------------------------------------------------------- small kernels
+template <int NO>
+__global__ void reward_kernel(const KernelParams p, float *feats_out, float *reward_out)
+{
+    constexpr int NOA = NO > 0 ? NO : 1;
+    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= p.n_problems) return;
+    const ocd_scenario_desc &d = p.d;
+    const int D = d.n_lanes + 4;
+    const float *ws = p.ego_states + b * (NO + 1) * 4;
+    float w[OCD_MAX_FEATURES];
+#pragma unroll
+    for (int k = 0; k < OCD_MAX_FEATURES; ++k) w[k] = (p.weights && k < D) ? p.weights[k] : 0.0f;
+    BumpGeom bg[NOA];
+    bg[0] = BumpGeom{0.0f, 1.0f, 0.0f, 1.0f};
+#pragma unroll
+    for (int j = 0; j < NO; ++j) bg[j] = bump_geom(ws[4 * (j + 1)], ws[4 * (j + 1) + 1], d.bump_half_x, d.bump_half_y);
+    float s_, c_;
+    sincos_(ws[3], s_, c_);
+    Q4 q;
+    const float r = reward_state<NO, false>(d, w, ws[0], ws[1], ws[2], s_, c_, bg, q,
+                                            feats_out ? feats_out + b * D : nullptr);
+    if (reward_out) reward_out[b] = r;
+}
+
+__global__ void math_kernel(const float *in, float *e, float *s, float *c, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = in[i];
+    if (e) e[i] = exp_(x);
+    float sv, cv;
+    sincos_(x, sv, cv);
+    if (s) s[i] = sv;
+    if (c) c[i] = cv;
+}
+
+} // namespace ocd
+
+// ---------------------------------------------------------------- launch table
+namespace ocd {
+
+template <int H, int NO>
+static hipError_t launch_mpc(const KernelParams &p, hipStream_t st)
+{
+    using G = Geo<H>;
+    const int K = p.K;
+    const long long blocks = (p.n_problems + G::SEGS - 1) / G::SEGS;
+    const size_t lds = ((size_t)K * G::NARR * G::SEGP + (size_t)2 * K * (G::SEGS + 1) * 4) * sizeof(float);
+    hipLaunchKernelGGL((mpc_kernel<H, NO>), dim3((unsigned)blocks), dim3(64 * K), lds, st, p);
+    return hipGetLastError();
+}
+
+#define OCD_CASE(HH, NN) if (H == HH && NO == NN) return launch_mpc<HH, NN>(p, st);
+
+hipError_t launch_mpc_dispatch(int H, int NO, const KernelParams &p, hipStream_t st, bool *supported)
+{
+    *supported = true;
+    OCD_KERNEL_TABLE(OCD_CASE)
+    *supported = false;
+    return hipSuccess;
+}
+
+hipError_t launch_reward(int NO, const KernelParams &p, float *feats, float *rew, hipStream_t st, bool *supported)
+{
+    *supported = true;
+    const unsigned bs = 256;
+    const unsigned nb = (unsigned)((p.n_problems + bs - 1) / bs);
+    switch (NO) {
+    case 0: hipLaunchKernelGGL((reward_kernel<0>), dim3(nb), dim3(bs), 0, st, p, feats, rew); break;
+    case 1: hipLaunchKernelGGL((reward_kernel<1>), dim3(nb), dim3(bs), 0, st, p, feats, rew); break;
+    case 2: hipLaunchKernelGGL((reward_kernel<2>), dim3(nb), dim3(bs), 0, st, p, feats, rew); break;
+    case 3: hipLaunchKernelGGL((reward_kernel<3>), dim3(nb), dim3(bs), 0, st, p, feats, rew); break;
+    default: *supported = false; return hipSuccess;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_math(const float *in, float *e, float *s, float *c, long long n, hipStream_t st)
+{
+    const unsigned bs = 256;
+    const unsigned nb = (unsigned)((n + bs - 1) / bs);
+    hipLaunchKernelGGL(math_kernel, dim3(nb), dim3(bs), 0, st, in, e, s, c, n);
+    return hipGetLastError();
+}
+
+} // namespace ocd

@@ -1,0 +1,152 @@
+"""Device-side plumbing around the C ABI: buffers, streams, handles.
+
+PyTorch-ROCm is used for device allocation, host<->device copies and stream
+handles only; every computation is a call into csrc/libocd_hip.so.  There is
+no CPU fallback: constructing an Engine without the library or without a GPU
+raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import abi
+from .scenarios import Scenario
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class Engine:
+    """One scenario handle bound to one GPU."""
+
+    def __init__(self, scenario: Scenario, device: Optional[str] = None):
+        self.lib = abi.load_hip_library()
+        if not torch.cuda.is_available():
+            raise RuntimeError("no MI355X visible: the planner runs on the GPU only (no CPU fallback)")
+        self.device = torch.device(device or f"cuda:{torch.cuda.current_device()}")
+        self.scenario = scenario
+        self.desc = scenario.desc
+        h = C.c_void_p()
+        abi.check(self.lib, self.lib.ocd_scenario_create(C.byref(self.desc), C.byref(h)))
+        self._h = h
+        plans = scenario.other_plans()
+        self._other_plans = None if plans is None else self._to_dev(plans)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self.lib.ocd_scenario_destroy(h)
+            self._h = None
+
+    # ------------------------------------------------------------------ helpers
+    def _to_dev(self, a, dtype=torch.float32) -> torch.Tensor:
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=dtype).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(self.device)
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _call(self, fn, *args):
+        with torch.cuda.device(self.device):
+            abi.check(self.lib, fn(*args))
+
+    # ------------------------------------------------------------------ entry points
+    def plan_batch(self, world_state, weights=None, other_plans="scenario", want_all: bool = False,
+                   to_numpy: bool = True) -> Dict[str, object]:
+        """NaivePlanner.generate_plan for a batch of world states [B, C, 4]."""
+        d = self.desc
+        ws = self._to_dev(world_state).reshape(-1, d.n_cars, 4)
+        B = ws.shape[0]
+        H, K = d.horizon, d.n_ctrl_inits
+        w = None if weights is None else self._to_dev(weights)
+        per = int(w is not None and w.dim() == 2)
+        if w is not None and per and w.shape[0] != B:
+            raise ValueError(f"weights has {w.shape[0]} rows for {B} world states")
+        if isinstance(other_plans, str):
+            op = self._other_plans
+        else:
+            op = None if other_plans is None else self._to_dev(other_plans).reshape(d.n_cars - 1, H, 2)
+        plans = torch.empty((B, H, 2), dtype=torch.float32, device=self.device)
+        loss = torch.empty((B,), dtype=torch.float32, device=self.device)
+        best = torch.empty((B,), dtype=torch.int32, device=self.device)
+        all_plans = torch.empty((B, K, H, 2), dtype=torch.float32, device=self.device) if want_all else None
+        all_losses = torch.empty((B, K), dtype=torch.float32, device=self.device) if want_all else None
+        self._call(self.lib.ocd_plan_batch, self._h, _ptr(ws), _ptr(w), per, _ptr(op), _ptr(plans), _ptr(loss),
+                   _ptr(best), _ptr(all_plans), _ptr(all_losses), B, self._stream())
+        out = dict(plans=plans, best_loss=loss, best_init=best)
+        if want_all:
+            out.update(all_plans=all_plans, all_losses=all_losses)
+        if to_numpy:
+            torch.cuda.synchronize(self.device)
+            out = {k: v.cpu().numpy() for k, v in out.items()}
+        return out
+
+    def rollout(self, init_states, cand_weights, ep_begin: int = 0, ep_end: Optional[int] = None,
+                want_traj: bool = False, to_numpy: bool = True) -> Dict[str, object]:
+        """Episodes e = (p*N + n)*S + s in [ep_begin, ep_end): MPC_ORD.eval_weights_for_init per sample.
+
+        cand_weights: [P, D] fp32, already normalised (scenarios.planner_weights_fp32).
+        """
+        d = self.desc
+        init = self._to_dev(init_states).reshape(-1, 4)
+        N = init.shape[0]
+        if cand_weights is None:
+            w, P = None, 1
+        else:
+            w = self._to_dev(cand_weights).reshape(-1, d.n_features)
+            P = w.shape[0]
+        E = P * N * d.n_samples
+        if ep_end is None:
+            ep_end = E
+        n = ep_end - ep_begin
+        T = d.episode_len
+        ret = torch.empty((max(n, 0),), dtype=torch.float32, device=self.device)
+        traj = torch.empty((n, T + 1, d.n_cars, 4), dtype=torch.float32, device=self.device) if want_traj else None
+        ctrl = torch.empty((n, T, 2), dtype=torch.float32, device=self.device) if want_traj else None
+        self._call(self.lib.ocd_rollout_episodes, self._h, _ptr(init), _ptr(w), P, N, ep_begin, ep_end,
+                   _ptr(ret), _ptr(traj), _ptr(ctrl), self._stream())
+        out = dict(returns=ret)
+        if want_traj:
+            out.update(traj=traj, ctrl=ctrl)
+        if to_numpy:
+            torch.cuda.synchronize(self.device)
+            out = {k: v.cpu().numpy() for k, v in out.items()}
+        return out
+
+    def time_rollout(self, init_dev: torch.Tensor, w_dev: torch.Tensor, ep_begin: int, ep_end: int,
+                     ret_dev: torch.Tensor, reps: int) -> float:
+        """Mean ms per launch over `reps` launches, HIP events on the launch stream (bench.py)."""
+        d = self.desc
+        N = init_dev.shape[0]
+        P = w_dev.shape[0]
+        ms = C.c_float(0.0)
+        self._call(self.lib.ocd_time_rollout, self._h, _ptr(init_dev), _ptr(w_dev), P, N, ep_begin, ep_end,
+                   _ptr(ret_dev), reps, C.byref(ms), self._stream())
+        return float(ms.value)
+
+    def reward_batch(self, world_state, weights):
+        d = self.desc
+        ws = self._to_dev(world_state).reshape(-1, d.n_cars, 4)
+        B = ws.shape[0]
+        w = self._to_dev(weights)
+        feats = torch.empty((B, d.n_features), dtype=torch.float32, device=self.device)
+        rew = torch.empty((B,), dtype=torch.float32, device=self.device)
+        self._call(self.lib.ocd_reward_batch, self._h, _ptr(ws), _ptr(w), _ptr(feats), _ptr(rew), B, self._stream())
+        torch.cuda.synchronize(self.device)
+        return feats.cpu().numpy(), rew.cpu().numpy()
+
+    def debug_math(self, x):
+        xin = self._to_dev(x).reshape(-1)
+        n = xin.numel()
+        e = torch.empty_like(xin)
+        s = torch.empty_like(xin)
+        c = torch.empty_like(xin)
+        self._call(self.lib.ocd_debug_math, _ptr(xin), _ptr(e), _ptr(s), _ptr(c), n, self._stream())
+        torch.cuda.synchronize(self.device)
+        return e.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy()
