@@ -121,6 +121,10 @@ def load_hip_library(path: Optional[str] = None) -> C.CDLL:
         raise FileNotFoundError(
             f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(the MI355X planner has no CPU fallback)")
+    # PyTorch-ROCm ships its own libamdhip64; import it first so that this library binds to the
+    # SAME HIP runtime (same SONAME, first one loaded wins) and torch's device pointers and
+    # streams are valid in it.  Two runtimes in one process do not share devices or memory.
+    import torch  # noqa: F401
     lib = C.CDLL(p)
     for name, restype, argtypes in HIP_SYMBOLS:
         fn = getattr(lib, name)  # AttributeError if the symbol is missing

@@ -14,10 +14,18 @@
 #include "../../include/ocd.h"
 #include "ocd_kernels.h"
 
+#define OCD_MAX_DEVICES 16
+#include <mutex>
+
 struct ocd_scenario {
     ocd_scenario_desc desc;
     int32_t K;
     int32_t D;
+    // The planner's fixed view of the scripted cars' plans (planner_car.py:58-80:
+    // plan[j] from index 0, then default_control) is a scenario constant; rollouts
+    // read it from a small device buffer owned by the handle, one per device.
+    std::mutex mu;
+    float *dev_plans[OCD_MAX_DEVICES];
 };
 
 namespace {
@@ -121,11 +129,18 @@ int32_t ocd_scenario_create(const ocd_scenario_desc *desc, ocd_scenario **out)
     s->desc = *desc;
     s->K = desc->extra_inits ? 6 : 3;
     s->D = desc->n_lanes + 4;
+    for (int i = 0; i < OCD_MAX_DEVICES; ++i) s->dev_plans[i] = nullptr;
     *out = s;
     return OCD_OK;
 }
 
-void ocd_scenario_destroy(ocd_scenario *scn) { delete scn; }
+void ocd_scenario_destroy(ocd_scenario *scn)
+{
+    if (!scn) return;
+    for (int i = 0; i < OCD_MAX_DEVICES; ++i)
+        if (scn->dev_plans[i]) (void)hipFree(scn->dev_plans[i]);
+    delete scn;
+}
 
 int32_t ocd_plan_batch(const ocd_scenario *scn, const float *world_state,
                        const float *weights, int32_t weights_per_problem, const float *other_plans,
@@ -185,29 +200,20 @@ static int32_t rollout_params(const ocd_scenario *scn, const float *init_states,
 
 } // extern "C"
 
-// The planner's fixed view of the scripted cars' plans (planner_car.py:58-80:
-// plan[j] from index 0, then default_control) is a scenario constant; rollouts
-// read it from a small device buffer cached per (scenario handle, device).
 namespace {
 
-struct PlanCache {
-    const ocd_scenario *scn = nullptr;
-    int device = -1;
-    float *dev = nullptr;
-};
-thread_local PlanCache g_plan_cache;
-
-int32_t scripted_plans_device(const ocd_scenario *scn, hipStream_t st, const float **out)
+int32_t scripted_plans_device(const ocd_scenario *scn_c, hipStream_t st, const float **out)
 {
     *out = nullptr;
+    ocd_scenario *scn = const_cast<ocd_scenario *>(scn_c);
     const ocd_scenario_desc &d = scn->desc;
     if (!d.check_plans || d.n_cars < 2) return OCD_OK;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return hip_fail(e, "hipGetDevice");
-    PlanCache &c = g_plan_cache;
-    if (c.scn == scn && c.device == dev && c.dev) { *out = c.dev; return OCD_OK; }
-    if (c.dev) { (void)hipFree(c.dev); c.dev = nullptr; }
+    if (dev < 0 || dev >= OCD_MAX_DEVICES) return fail(OCD_ERR_UNSUPPORTED, "device ordinal %d >= %d", dev, OCD_MAX_DEVICES);
+    std::lock_guard<std::mutex> lock(scn->mu);
+    if (scn->dev_plans[dev]) { *out = scn->dev_plans[dev]; return OCD_OK; }
     const int H = d.horizon, NO = d.n_cars - 1;
     float host[OCD_MAX_OTHERS * OCD_MAX_HORIZON * 2];
     for (int j = 0; j < NO; ++j)
@@ -217,13 +223,14 @@ int32_t scripted_plans_device(const ocd_scenario *scn, hipStream_t st, const flo
             host[(j * H + t) * 2 + 1] = src[1];
         }
     const size_t bytes = sizeof(float) * NO * H * 2;
-    e = hipMalloc(&c.dev, bytes);
+    float *buf = nullptr;
+    e = hipMalloc(&buf, bytes);
     if (e != hipSuccess) return hip_fail(e, "hipMalloc(scripted plans)");
-    e = hipMemcpyAsync(c.dev, host, bytes, hipMemcpyHostToDevice, st);
+    e = hipMemcpyAsync(buf, host, bytes, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);   // host[] is a stack buffer
-    if (e != hipSuccess) return hip_fail(e, "hipMemcpy(scripted plans)");
-    c.scn = scn; c.device = dev;
-    *out = c.dev;
+    if (e != hipSuccess) { (void)hipFree(buf); return hip_fail(e, "hipMemcpy(scripted plans)"); }
+    scn->dev_plans[dev] = buf;
+    *out = buf;
     return OCD_OK;
 }
 

@@ -1,0 +1,68 @@
+"""Sharding of the (candidate x init x sample) episode batch across ranks.
+
+The reference's only parallel axis is a multiprocessing.Pool over init groups
+(experiments/run_mpc_ord.py:83-90); episodes are fully independent
+(interact_drive/reward_design/mpc_ord.py:128-137).  Here rank g takes the
+contiguous candidate block [g*P/G, (g+1)*P/G) x all inits x all samples, so a
+candidate's reduction over inits stays on one rank and in init order; the data
+path has no collective.  Per generation there is exactly one collective: an
+all-gather of the fp32 per-episode returns (<= 128 KiB in total at the largest
+BASELINE config -- latency-bound, so a single-shot all-gather, not a chunked
+ring).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def candidate_block(P: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous candidate range of `rank`; sizes differ by at most one."""
+    base, rem = divmod(P, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def episode_range(P: int, N: int, S: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Flat episode range e = (p*N + n)*S + s owned by `rank`."""
+    lo, hi = candidate_block(P, world_size, rank)
+    return lo * N * S, hi * N * S
+
+
+def gather_returns(local: torch.Tensor, P: int, N: int, S: int, group: Optional[dist.ProcessGroup] = None
+                   ) -> torch.Tensor:
+    """All-gather the per-episode returns of every rank into the full [P*N*S] vector (on every rank)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    ws = dist.get_world_size(group)
+    sizes = [(candidate_block(P, ws, r)[1] - candidate_block(P, ws, r)[0]) * N * S for r in range(ws)]
+    m = max(sizes)
+    if local.numel() != sizes[dist.get_rank(group)]:
+        raise ValueError(f"rank holds {local.numel()} returns, expected {sizes[dist.get_rank(group)]}")
+    padded = local if local.numel() == m else torch.cat([local, local.new_zeros(m - local.numel())])
+    out = torch.empty(ws * m, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, padded.contiguous(), group=group)
+    if all(s == m for s in sizes):
+        return out
+    return torch.cat([out[r * m: r * m + sizes[r]] for r in range(ws)])
+
+
+def fitness_from_returns(returns, P: int, N: int, S: int) -> np.ndarray:
+    """[P*N*S] fp32 sample rewards -> [P] CMA-ES costs, with the reference's accumulation types.
+
+    Per (candidate, init): samples are summed in fp32 (TensorFlow scalars, mpc_ord.py:102);
+    across inits the Python sum promotes to float64 (np.float32 + int under NumPy 1.x value-based
+    casting, mpc_ord.py:126,137); then / num_samples and negated (mpc_ord.py:139,151).
+    """
+    r = np.asarray(returns, dtype=np.float32).reshape(P, N, S)
+    per_init = np.zeros((P, N), dtype=np.float32)
+    for s in range(S):
+        per_init = (per_init + r[:, :, s]).astype(np.float32)
+    total = np.zeros(P, dtype=np.float64)
+    for n in range(N):
+        total = total + per_init[:, n].astype(np.float64)
+    total = total / S
+    return -total
