@@ -37,12 +37,33 @@ def algorithmic_per_episode(desc):
     return nbytes, flops
 
 
+def usable_cores():
+    """CPU threads this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:            # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()
+            if q != "max":
+                n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = int(f.read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(scn, inits, w32, budget_s=15.0):
     """The CPU oracle (kind "port") timed on this host's cores on a bounded sample of the workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     orc = oracle_lib.load()
-    cores = os.cpu_count() or 1
+    cores = min(usable_cores(), int(os.environ.get("OCD_CPU_THREADS", "64")))
     P, N = w32.shape[0], inits.shape[0]
     E = P * N * scn.desc.n_samples
     # calibrate on a few episodes, then size the sample for ~budget_s of wall time
