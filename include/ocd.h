@@ -176,6 +176,32 @@ int32_t ocd_rollout_episodes(const ocd_scenario *scn,
                              void *hip_stream);
 
 /*
+ * The same episode loop started from arbitrary world states instead of
+ * world.reset(): n_steps control steps from world step index `first_step`
+ * (selects the scripted cars' plan entries, fixed_plan_car.py:25-31, and the
+ * teleport step) with the reset outcome `sample`.  With n_steps = 1 this is
+ * one CarWorld.step() (world.py:79-109): returns_out is the designer reward
+ * of the pre-step state, ctrl_out the ego control PlannerCar._get_next_control
+ * chose, traj_out[.,1] the state after Car.step.
+ *
+ *   world_state [B, C, 4]; weights [B, D] or [D] (weights_per_problem);
+ *   returns_out [B]; traj_out [B, n_steps+1, C, 4] or NULL; ctrl_out [B, n_steps, 2] or NULL.
+ */
+int32_t ocd_rollout_from_state(const ocd_scenario *scn, const float *world_state,
+                               const float *weights, int32_t weights_per_problem,
+                               int32_t first_step, int32_t n_steps, int32_t sample,
+                               float *returns_out, float *traj_out, float *ctrl_out,
+                               int64_t B, void *hip_stream);
+
+/*
+ * car_dynamics_step / next_car_state for B (state, control) pairs
+ * (interact_drive/simulation_utils.py:9-21,73-123; get_dynamics_fn :321-326).
+ *   states [B, 4], controls [B, 2], next_out [B, 4]; dt_sq = fp32(dt ** 2).
+ */
+int32_t ocd_dynamics_batch(const float *states, const float *controls, float dt, float dt_sq, float friction,
+                           float *next_out, int64_t B, void *hip_stream);
+
+/*
  * Reward features and reward of B world states (no planning).  Replaces
  * ThreeLaneTestCar.features / LinearRewardCar.reward_fn evaluated on a grid,
  * e.g. the visualiser's heat map (interact_drive/visualizer.py:211-238).

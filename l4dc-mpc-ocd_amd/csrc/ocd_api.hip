@@ -158,6 +158,7 @@ int32_t ocd_plan_batch(const ocd_scenario *scn, const float *world_state,
     ocd::KernelParams p;
     base_params(scn, p);
     p.mode = ocd::OCD_MODE_PLAN;
+    p.T = 1;
     p.ego_states = world_state;
     p.weights = weights;
     p.weights_per_problem = weights_per_problem;
@@ -195,6 +196,7 @@ static int32_t rollout_params(const ocd_scenario *scn, const float *init_states,
     p.n_problems = ep_end - ep_begin;
     p.ep_begin = ep_begin;
     p.N = N;
+    p.T = scn->desc.episode_len;
     return OCD_OK;
 }
 
@@ -253,6 +255,56 @@ int32_t ocd_rollout_episodes(const ocd_scenario *scn, const float *init_states, 
     st = rollout_params(scn, init_states, cand_weights, P, N, ep_begin, ep_end, returns_out, traj_out, ctrl_out, plans, p);
     if (st != OCD_OK) return st;
     return launch(scn, p, hip_stream);
+}
+
+int32_t ocd_rollout_from_state(const ocd_scenario *scn, const float *world_state,
+                               const float *weights, int32_t weights_per_problem,
+                               int32_t first_step, int32_t n_steps, int32_t sample,
+                               float *returns_out, float *traj_out, float *ctrl_out,
+                               int64_t B, void *hip_stream)
+{
+    if (!scn) return fail(OCD_ERR_INVALID_ARG, "scenario is NULL");
+    if (B < 0 || n_steps < 0 || first_step < 0) return fail(OCD_ERR_INVALID_ARG, "negative B / n_steps / first_step");
+    if (sample < 0 || sample >= OCD_MAX_SAMPLES) return fail(OCD_ERR_INVALID_ARG, "sample %d out of [0,%d)", sample, OCD_MAX_SAMPLES);
+    if (B == 0) return OCD_OK;
+    if (!world_state || !returns_out) return fail(OCD_ERR_INVALID_ARG, "world_state / returns_out is NULL");
+    if (scn->desc.reward_kind == OCD_REWARD_LANE_FEATURES && !weights)
+        return fail(OCD_ERR_INVALID_ARG, "weights is NULL for a lane-feature reward");
+    int32_t st = need_device();
+    if (st != OCD_OK) return st;
+    const float *plans = nullptr;
+    st = scripted_plans_device(scn, (hipStream_t)hip_stream, &plans);
+    if (st != OCD_OK) return st;
+    ocd::KernelParams p;
+    base_params(scn, p);
+    p.mode = ocd::OCD_MODE_ROLLOUT;
+    p.from_state = 1;
+    p.ego_states = world_state;
+    p.weights = weights;
+    p.weights_per_problem = weights_per_problem;
+    p.other_plans = plans;
+    p.returns_out = returns_out;
+    p.traj_out = traj_out;
+    p.ctrl_out = ctrl_out;
+    p.n_problems = B;
+    p.N = 1;
+    p.T = n_steps;
+    p.t0 = first_step;
+    p.sample_fixed = sample;
+    return launch(scn, p, hip_stream);
+}
+
+int32_t ocd_dynamics_batch(const float *states, const float *controls, float dt, float dt_sq, float friction,
+                           float *next_out, int64_t B, void *hip_stream)
+{
+    if (B < 0) return fail(OCD_ERR_INVALID_ARG, "B < 0");
+    if (B == 0) return OCD_OK;
+    if (!states || !controls || !next_out) return fail(OCD_ERR_INVALID_ARG, "NULL pointer");
+    int32_t st = need_device();
+    if (st != OCD_OK) return st;
+    hipError_t e = ocd::launch_dynamics(states, controls, dt, dt_sq, friction, next_out, B, (hipStream_t)hip_stream);
+    if (e != hipSuccess) return hip_fail(e, "dynamics_kernel launch");
+    return OCD_OK;
 }
 
 int32_t ocd_reward_batch(const ocd_scenario *scn, const float *world_state, const float *weights,

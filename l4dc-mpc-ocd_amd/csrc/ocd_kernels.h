@@ -13,7 +13,7 @@ enum { OCD_MODE_ROLLOUT = 0, OCD_MODE_PLAN = 1 };
 // through scalar loads, so scenario constants cost no vector registers).
 struct KernelParams {
     ocd_scenario_desc d;
-    const float *ego_states;   // ROLLOUT: init_states [N,4];  PLAN: world_state [B,C,4]
+    const float *ego_states;   // ROLLOUT: init_states [N,4];  PLAN / ROLLOUT-from-state: world_state [B,C,4]
     const float *weights;      // ROLLOUT: [P,D];  PLAN: [B,D] or [D]
     const float *other_plans;  // [C-1,H,2] or nullptr (constant-velocity model)
     float *returns_out;        // ROLLOUT [n]
@@ -31,6 +31,10 @@ struct KernelParams {
     int32_t mode;
     int32_t weights_per_problem;
     int32_t K;                 // control initialisations = wavefronts per workgroup
+    int32_t T;                 // control steps to run (ROLLOUT); 1 in PLAN mode
+    int32_t t0;                // world step index of the first control step (scripted plans, teleport)
+    int32_t from_state;        // ROLLOUT: 1 = every problem starts from its own world_state [B,C,4]
+    int32_t sample_fixed;      // from_state: which world.reset() outcome (teleported car) applies
 };
 
 // (horizon, scripted cars) pairs with a compiled kernel.  Horizons 5/6: the
@@ -45,5 +49,7 @@ struct KernelParams {
 hipError_t launch_mpc_dispatch(int H, int NO, const KernelParams &p, hipStream_t st, bool *supported);
 hipError_t launch_reward(int NO, const KernelParams &p, float *feats, float *rew, hipStream_t st, bool *supported);
 hipError_t launch_math(const float *in, float *e, float *s, float *c, long long n, hipStream_t st);
+hipError_t launch_dynamics(const float *states, const float *controls, float dt, float dt_sq, float friction,
+                           float *out, long long n, hipStream_t st);
 
 } // namespace ocd

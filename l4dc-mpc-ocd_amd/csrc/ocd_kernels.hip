@@ -343,7 +343,7 @@ mpc_kernel(const KernelParams p)
     float w[OCD_MAX_FEATURES];
     int sample = 0;
     long long e_glob = 0;
-    if (p.mode == OCD_MODE_ROLLOUT) {
+    if (p.mode == OCD_MODE_ROLLOUT && !p.from_state) {
         e_glob = p.ep_begin + prob;           // flat (p, n, s) index
         const long long s_ = e_glob % p.S, n_ = (e_glob / p.S) % p.N, p_ = e_glob / ((long long)p.S * p.N);
         sample = (int)s_;
@@ -367,12 +367,13 @@ mpc_kernel(const KernelParams p)
         const float *wp = p.weights ? (p.weights + (p.weights_per_problem ? prob * D : 0)) : nullptr;
 #pragma unroll
         for (int k = 0; k < OCD_MAX_FEATURES; ++k) w[k] = (wp && k < D) ? wp[k] : 0.0f;
+        sample = p.sample_fixed;
     }
     float wd[OCD_MAX_FEATURES];               // designer weights (uniform)
 #pragma unroll
     for (int k = 0; k < OCD_MAX_FEATURES; ++k) wd[k] = d.designer_weights[k];
 
-    const int T = (p.mode == OCD_MODE_ROLLOUT) ? d.episode_len : 1;
+    const int T = p.T;
     float G_ret = 0.0f;
     const BumpGeom bg0 = {0.0f, 1.0f, 0.0f, 1.0f};
 
@@ -388,7 +389,7 @@ mpc_kernel(const KernelParams p)
     for (int step = 0; step < T; ++step) {
         if (p.mode == OCD_MODE_ROLLOUT) {
             // ReplanningCarWorld.step: self.t += 1; teleport when self.t == critical_t
-            if (d.teleport_step > 0 && (step + 1) == d.teleport_step) {
+            if (d.teleport_step > 0 && (p.t0 + step + 1) == d.teleport_step) {
                 const int car = d.teleport_car[sample];
 #pragma unroll
                 for (int j = 0; j < NO; ++j) {
@@ -643,9 +644,10 @@ mpc_kernel(const KernelParams p)
             ex = nx; ey = ny; ev = nv; eth = nth;
 #pragma unroll
             for (int j = 0; j < NO; ++j) {
-                const bool in_plan = step < d.other_plan_len[j];
-                const float u0 = in_plan ? d.other_plan[j][step & (OCD_MAX_PLAN - 1)][0] : d.other_default[j][0];
-                const float u1 = in_plan ? d.other_plan[j][step & (OCD_MAX_PLAN - 1)][1] : d.other_default[j][1];
+                const int gstep = p.t0 + step;    // FixedPlanCar.t (fixed_plan_car.py:25-31)
+                const bool in_plan = gstep < d.other_plan_len[j];
+                const float u0 = in_plan ? d.other_plan[j][gstep & (OCD_MAX_PLAN - 1)][0] : d.other_default[j][0];
+                const float u1 = in_plan ? d.other_plan[j][gstep & (OCD_MAX_PLAN - 1)][1] : d.other_default[j][1];
                 float s_, c_;
                 sincos_(oth[j], s_, c_);
                 dyn_step(ox[j], oy[j], ov[j], oth[j], c_, s_, u0, u1, dt, dt2, d.other_friction[j], nx, ny, nv, nth);
@@ -694,6 +696,20 @@ __global__ void reward_kernel(const KernelParams p, float *feats_out, float *rew
     const float r = reward_state<NO, false>(d, w, ws[0], ws[1], ws[2], s_, c_, bg, q,
                                             feats_out ? feats_out + b * D : nullptr);
     if (reward_out) reward_out[b] = r;
+}
+
+// car_dynamics_step for a batch of (state, control) pairs (simulation_utils.py:9-21,73-123)
+__global__ void dynamics_kernel(const float *st, const float *u, float dt, float dt2, float fr, float *out, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 s4 = reinterpret_cast<const float4 *>(st)[i];
+    const float2 u2 = reinterpret_cast<const float2 *>(u)[i];
+    float s_, c_;
+    sincos_(s4.w, s_, c_);
+    float4 o;
+    dyn_step(s4.x, s4.y, s4.z, s4.w, c_, s_, u2.x, u2.y, dt, dt2, fr, o.x, o.y, o.z, o.w);
+    reinterpret_cast<float4 *>(out)[i] = o;
 }
 
 __global__ void math_kernel(const float *in, float *e, float *s, float *c, long long n)
@@ -746,6 +762,15 @@ hipError_t launch_reward(int NO, const KernelParams &p, float *feats, float *rew
     case 3: hipLaunchKernelGGL((reward_kernel<3>), dim3(nb), dim3(bs), 0, st, p, feats, rew); break;
     default: *supported = false; return hipSuccess;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_dynamics(const float *states, const float *controls, float dt, float dt_sq, float friction,
+                           float *out, long long n, hipStream_t st)
+{
+    const unsigned bs = 256;
+    const unsigned nb = (unsigned)((n + bs - 1) / bs);
+    hipLaunchKernelGGL(dynamics_kernel, dim3(nb), dim3(bs), 0, st, states, controls, dt, dt_sq, friction, out, n);
     return hipGetLastError();
 }
 

@@ -21,27 +21,14 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-class Engine:
-    """One scenario handle bound to one GPU."""
+class DeviceOps:
+    """Scenario-independent device entry points (dynamics, math probes) on one GPU."""
 
-    def __init__(self, scenario: Scenario, device: Optional[str] = None):
+    def __init__(self, device: Optional[str] = None):
         self.lib = abi.load_hip_library()
         if not torch.cuda.is_available():
             raise RuntimeError("no MI355X visible: the planner runs on the GPU only (no CPU fallback)")
         self.device = torch.device(device or f"cuda:{torch.cuda.current_device()}")
-        self.scenario = scenario
-        self.desc = scenario.desc
-        h = C.c_void_p()
-        abi.check(self.lib, self.lib.ocd_scenario_create(C.byref(self.desc), C.byref(h)))
-        self._h = h
-        plans = scenario.other_plans()
-        self._other_plans = None if plans is None else self._to_dev(plans)
-
-    def __del__(self):
-        h = getattr(self, "_h", None)
-        if h:
-            self.lib.ocd_scenario_destroy(h)
-            self._h = None
 
     # ------------------------------------------------------------------ helpers
     def _to_dev(self, a, dtype=torch.float32) -> torch.Tensor:
@@ -55,6 +42,59 @@ class Engine:
     def _call(self, fn, *args):
         with torch.cuda.device(self.device):
             abi.check(self.lib, fn(*args))
+
+    def dynamics_batch(self, states, controls, dt: float, friction: float):
+        """next_car_state for [B,4] states and [B,2] controls (simulation_utils.py:73-123)."""
+        st = self._to_dev(states).reshape(-1, 4)
+        u = self._to_dev(controls).reshape(-1, 2)
+        if u.shape[0] == 1 and st.shape[0] > 1:
+            u = u.expand(st.shape[0], 2).contiguous()
+        out = torch.empty_like(st)
+        self._call(self.lib.ocd_dynamics_batch, _ptr(st), _ptr(u), float(np.float32(dt)),
+                   float(np.float32(float(dt) ** 2)), float(np.float32(friction)), _ptr(out), st.shape[0],
+                   self._stream())
+        torch.cuda.synchronize(self.device)
+        return out.cpu().numpy()
+
+    def debug_math(self, x):
+        xin = self._to_dev(x).reshape(-1)
+        n = xin.numel()
+        e = torch.empty_like(xin)
+        s = torch.empty_like(xin)
+        c = torch.empty_like(xin)
+        self._call(self.lib.ocd_debug_math, _ptr(xin), _ptr(e), _ptr(s), _ptr(c), n, self._stream())
+        torch.cuda.synchronize(self.device)
+        return e.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy()
+
+
+_default_ops: Optional[DeviceOps] = None
+
+
+def default_ops() -> DeviceOps:
+    global _default_ops
+    if _default_ops is None:
+        _default_ops = DeviceOps()
+    return _default_ops
+
+
+class Engine(DeviceOps):
+    """One scenario handle bound to one GPU."""
+
+    def __init__(self, scenario: Scenario, device: Optional[str] = None):
+        super().__init__(device)
+        self.scenario = scenario
+        self.desc = scenario.desc
+        h = C.c_void_p()
+        abi.check(self.lib, self.lib.ocd_scenario_create(C.byref(self.desc), C.byref(h)))
+        self._h = h
+        plans = scenario.other_plans()
+        self._other_plans = None if plans is None else self._to_dev(plans)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self.lib.ocd_scenario_destroy(h)
+            self._h = None
 
     # ------------------------------------------------------------------ entry points
     def plan_batch(self, world_state, weights=None, other_plans="scenario", want_all: bool = False,
@@ -119,6 +159,25 @@ class Engine:
             out = {k: v.cpu().numpy() for k, v in out.items()}
         return out
 
+    def rollout_from_state(self, world_state, weights, first_step: int, n_steps: int, sample: int = 0,
+                           to_numpy: bool = True) -> Dict[str, object]:
+        """n_steps CarWorld.step() calls from arbitrary world states [B, C, 4] (world step index first_step)."""
+        d = self.desc
+        ws = self._to_dev(world_state).reshape(-1, d.n_cars, 4)
+        B = ws.shape[0]
+        w = None if weights is None else self._to_dev(weights)
+        per = int(w is not None and w.dim() == 2)
+        ret = torch.empty((B,), dtype=torch.float32, device=self.device)
+        traj = torch.empty((B, n_steps + 1, d.n_cars, 4), dtype=torch.float32, device=self.device)
+        ctrl = torch.empty((B, n_steps, 2), dtype=torch.float32, device=self.device)
+        self._call(self.lib.ocd_rollout_from_state, self._h, _ptr(ws), _ptr(w), per, first_step, n_steps, sample,
+                   _ptr(ret), _ptr(traj), _ptr(ctrl), B, self._stream())
+        out = dict(returns=ret, traj=traj, ctrl=ctrl)
+        if to_numpy:
+            torch.cuda.synchronize(self.device)
+            out = {k: v.cpu().numpy() for k, v in out.items()}
+        return out
+
     def time_rollout(self, init_dev: torch.Tensor, w_dev: torch.Tensor, ep_begin: int, ep_end: int,
                      ret_dev: torch.Tensor, reps: int) -> float:
         """Mean ms per launch over `reps` launches, HIP events on the launch stream (bench.py)."""
@@ -140,13 +199,3 @@ class Engine:
         self._call(self.lib.ocd_reward_batch, self._h, _ptr(ws), _ptr(w), _ptr(feats), _ptr(rew), B, self._stream())
         torch.cuda.synchronize(self.device)
         return feats.cpu().numpy(), rew.cpu().numpy()
-
-    def debug_math(self, x):
-        xin = self._to_dev(x).reshape(-1)
-        n = xin.numel()
-        e = torch.empty_like(xin)
-        s = torch.empty_like(xin)
-        c = torch.empty_like(xin)
-        self._call(self.lib.ocd_debug_math, _ptr(xin), _ptr(e), _ptr(s), _ptr(c), n, self._stream())
-        torch.cuda.synchronize(self.device)
-        return e.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy()

@@ -1,0 +1,2 @@
+from .mpc_ord import MPC_ORD, finite_horizon_env  # noqa: F401
+from .utils import evaluate_weights  # noqa: F401

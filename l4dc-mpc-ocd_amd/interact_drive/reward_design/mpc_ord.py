@@ -1,0 +1,174 @@
+"""MPC_ORD: the reward-design fitness loop.  Mirrors interact_drive/reward_design/mpc_ord.py:10-207.
+
+``eval_weights`` keeps the reference's scalar signature; ``eval_population`` is the batched entry
+point ([P, D] -> [P]) that one CMA-ES generation needs and the GPU is built for.  With
+torch.distributed initialised (backend "nccl" = RCCL), candidates are sharded over the ranks and the
+per-episode returns are all-gathered once per call (sharding.py).
+"""
+import pickle
+import time
+
+import numpy as np
+
+from .cmaes import CMAES
+from .. import experiments  # noqa: F401
+from ..experiments.merging import ThreeLaneCarWorld, ThreeLaneTestCar
+from ..experiments._sampling import make_get_init_state
+from ..car import FixedVelocityCar
+from .._describe import describe, engine_for
+from ... import sharding
+from ...scenarios import planner_weights_fp32
+
+
+class list2(list):  # mutable list that can carry a .seed attribute (mpc_ord.py:10-12)
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+
+
+class MPC_ORD:
+    def __init__(self, world, car, init_car_states, designer_horizon, save_path=None, num_samples=1):
+        self.world = world
+        self.car = car
+        self.designer_horizon = designer_horizon
+        self.init_car_states = init_car_states
+        self.save_path = save_path
+        self.designer_weights = car.weights / np.linalg.norm(car.weights)
+        self.weight_dim = len(car.weights)
+        self.history = list2()
+        self.iter = 0
+        self.should_save_history = False
+        self.done = False
+        self.num_samples = num_samples
+        self.verbose = False
+        self.last_returns = None
+
+    # ------------------------------------------------------------------ GPU plumbing
+    def _engine(self):
+        pa = self.car.planner_args
+        desc = describe(self.world, self.car, self.car.horizon, pa.get("learning_rate", 0.1),
+                        pa.get("n_iter", 100), pa.get("extra_inits", False),
+                        episode_len=self.designer_horizon, n_samples=self.num_samples,
+                        designer_weights=self.designer_weights)
+        return engine_for(desc)
+
+    def _returns(self, inits, weights_2d):
+        """fp32 sample rewards [P, N, S] of every (candidate, init, sample) episode; sharded when distributed."""
+        import torch
+        import torch.distributed as dist
+        eng = self._engine()
+        w32 = np.stack([planner_weights_fp32(w) for w in weights_2d])
+        init = np.asarray(inits, dtype=np.float32).reshape(-1, 4)
+        P, N, S = w32.shape[0], init.shape[0], self.num_samples
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            e0, e1 = sharding.episode_range(P, N, S, dist.get_world_size(), dist.get_rank())
+            local = eng.rollout(init, w32, ep_begin=e0, ep_end=e1, to_numpy=False)["returns"]
+            full = sharding.gather_returns(local, P, N, S)
+            ret = full.cpu().numpy()
+        else:
+            ret = eng.rollout(init, w32)["returns"]
+        # keep world.reset() side effects in step with the reference (ReplanningCarWorld toggles per reset)
+        for _ in range(N * S):
+            if hasattr(self.world, "unlucky_car_idx"):
+                self.world.unlucky_car_idx = 2 if self.world.unlucky_car_idx == 1 else 1
+        return ret.reshape(P, N, S)
+
+    # ------------------------------------------------------------------ reference API
+    def eval_weights_for_init(self, init, weights, render, heatmap_show=False):
+        """Designer return of one init (summed over samples), mpc_ord.py:67-106."""
+        if render:
+            raise NotImplementedError("rendering is outside the accelerated planner path")
+        weights = np.asarray(weights)
+        if weights.ndim == 2:
+            weights = weights[0]
+        r = self._returns([init], [weights])[0, 0]
+        designer_reward = np.float32(0)
+        for s in range(self.num_samples):
+            designer_reward = np.float32(designer_reward + r[s])
+        self.car.weights = weights / np.linalg.norm(weights)
+        self.car.init_state = type(self.car.state)(init)
+        return designer_reward
+
+    def eval_population(self, weights_2d):
+        """[P, D] candidate weights -> [P] costs (-expected designer return), one launch per rank."""
+        W = np.asarray(weights_2d, dtype=np.float64).reshape(-1, self.weight_dim)
+        ret = self._returns(self.init_car_states, W)
+        self.last_returns = ret
+        P, N, S = ret.shape
+        cost = sharding.fitness_from_returns(ret.reshape(-1), P, N, S)
+        for p in range(P):
+            wn = W[p] / np.linalg.norm(W[p])
+            self.history.append((wn, -cost[p]))
+            self.iter += 1
+        if self.should_save_history and self.save_path is not None:
+            self.save_history()
+        return cost
+
+    def eval_weights(self, weights, gif=None, heatmap_show=False):
+        """The CMA-ES fitness callable of the reference (mpc_ord.py:109-151): one candidate -> cost."""
+        if gif:
+            raise NotImplementedError("gif rendering is outside the accelerated planner path")
+        if isinstance(weights, list):
+            weights = np.array(weights)
+        if weights.ndim == 2:
+            weights = weights[0]
+        if self.verbose:
+            print('ITERATION', self.iter)
+            print('eval', weights / np.linalg.norm(weights))
+        return float(self.eval_population(weights[None])[0])
+
+    def optimize_cmaes(self, seed=1, sigma0=0.1, popsize=None, maxiter=None, maxfevals=None):
+        """mpc_ord.py:33-45, with whole generations evaluated per launch."""
+        self.history.seed = seed
+        assert seed != 0
+        assert not self.done
+        self.should_save_history = True
+        self.eval_weights(self.designer_weights)                       # "Iteration 0" baseline
+        es = CMAES(list(self.designer_weights), sigma0, popsize=popsize, seed=seed)
+        self.generation_seconds = []
+        while True:
+            X = es.ask()
+            t0 = time.perf_counter()
+            f = self.eval_population(X)
+            self.generation_seconds.append(time.perf_counter() - t0)
+            es.tell(X, f)
+            if es.stop(maxiter=maxiter, last_fitness=f) or (maxfevals and es.counteval >= maxfevals):
+                break
+        self.should_save_history = False
+        self.done = True
+        self.es = es
+        return es.best_x
+
+    def optimize_random_search(self, n_iter=1000, seed=1):
+        """mpc_ord.py:47-65: same candidate stream (np.random.rand under np.random.seed), one launch."""
+        self.history.seed = seed
+        assert not self.done
+        self.should_save_history = True
+        self.iter = 0
+        self.eval_weights(self.designer_weights)
+        np.random.seed(seed)
+        W = np.stack([np.random.rand(*self.designer_weights.shape) * 2 - 1 for _ in range(n_iter)])
+        self.eval_population(W)
+        self.should_save_history = False
+        self.done = True
+        return max(self.history, key=lambda a: a[1])
+
+    def save_history(self):
+        assert self.save_path is not None
+        with open(self.save_path, 'wb') as file:
+            pickle.dump(self.history, file)
+
+
+def finite_horizon_env(horizon=5, env_seeds=[1], debug=True, extra_inits=False):
+    """mpc_ord.py:162-207."""
+    get_init_state = make_get_init_state((0, 0.04, (-0.1, 0.1)), (-0.9, 0.02, (-0.95, -0.85)),
+                                         (0.8, 0.03, (0.7, 0.9)))
+    init_states = [get_init_state(s) for s in env_seeds]
+    world = ThreeLaneCarWorld(visualizer_args=dict(name="Switch Lanes"))
+    pa = dict(n_iter=200 if horizon == 6 else 100, extra_inits=extra_inits)
+    our_car = ThreeLaneTestCar(world, init_state=init_states[0], horizon=horizon,
+                               weights=np.array([-5, 0., 0., 0., -6., -50, -50]), debug=debug, planner_args=pa)
+    other_car = FixedVelocityCar(world, np.array([0, -0.6, 0.5, np.pi / 2]), horizon=horizon, color="gray",
+                                 opacity=0.8, debug=debug, planner_args=pa)
+    world.add_cars([our_car, other_car])
+    world.reset()
+    return our_car, world, init_states

@@ -140,6 +140,8 @@ def _base_desc(horizon: int, n_iter: int, extra_inits: bool, episode_len: int) -
     d.teleport_step = 0
     for s in range(abi.OCD_MAX_SAMPLES):
         d.teleport_car[s] = -1
+    for k, v in enumerate((10., 0., 0., 0.)):      # replanning_world.py:34 (unused unless teleport_step > 0)
+        d.teleport_state[k] = v
     dt = 0.1                                  # CarWorld.dt (world.py:19)
     d.dt = dt
     d.dt_sq = np.float32(dt ** 2)             # dt ** 2 squared as a Python float (simulation_utils.py:14)
@@ -232,8 +234,6 @@ def replanning(horizon: int = 5, n_iter: int = 100) -> Scenario:
     d.teleport_step = 4
     for s in range(abi.OCD_MAX_SAMPLES):
         d.teleport_car[s] = 1 + (s % 2)
-    for k, v in enumerate((10., 0., 0., 0.)):
-        d.teleport_state[k] = v
     raw = np.array([-3, 0, 0, -2, -10, -10], dtype=np.float32)
     _set_designer(d, designer_weights_fp32(raw, raw_dtype=np.float32, pre_normalised=True))
     return Scenario(

@@ -467,16 +467,13 @@ int32_t ocd_plan_batch_cpu(const ocd_scenario_desc *d, const float *world_state,
     return OCD_OK;
 }
 
-/* ---- one episode (mpc_ord.py:87-104 over world.py:97-109) ---- */
-static float episode(const ocd_scenario_desc *d, const float *init, const float *w_plan, int sample,
-                     float *traj /*[T+1,C,4] or NULL*/, float *ctrl /*[T,2] or NULL*/)
+/* ---- control steps of the world (mpc_ord.py:87-104 over world.py:97-109) ----
+ * ws: world state [C,4] at world step index t0 (updated in place); runs T steps. */
+static float run_steps(const ocd_scenario_desc *d, float *ws, const float *w_plan, int sample, int t0, int T,
+                       float *traj /*[T+1,C,4] or NULL*/, float *ctrl /*[T,2] or NULL*/)
 {
-    const int C = d->n_cars, H = d->horizon, T = d->episode_len, NO = C - 1;
+    const int C = d->n_cars, H = d->horizon, NO = C - 1;
     const float dt = d->dt, dt2 = d->dt_sq;
-    float ws[OCD_MAX_CARS * 4];
-    /* world.reset(): every car back to its init_state; FixedPlanCar.t = 0 */
-    memcpy(ws, init, 4 * sizeof(float));
-    for (int j = 0; j < NO; ++j) memcpy(ws + 4 * (j + 1), d->other_init[j], 4 * sizeof(float));
     /* PlannerCar._get_next_control: plan[j] from index 0 at EVERY step (planner_car.py:66-75) */
     float oplans[MAXO * MAXH * 2];
     if (d->check_plans) {
@@ -489,7 +486,8 @@ static float episode(const ocd_scenario_desc *d, const float *init, const float 
     float G = 0.0f;
     float plan[MAXH * 2];
     if (traj) memcpy(traj, ws, sizeof(float) * C * 4);
-    for (int i = 0; i < T; ++i) {
+    for (int k = 0; k < T; ++k) {
+        const int i = t0 + k;
         /* ReplanningCarWorld.step: self.t += 1; if self.t == critical_t: teleport */
         if (d->teleport_step > 0 && (i + 1) == d->teleport_step) {
             const int car = d->teleport_car[sample];
@@ -500,7 +498,7 @@ static float episode(const ocd_scenario_desc *d, const float *init, const float 
         G = G + r;                               /* sample_reward = 0; sample_reward += ... */
         /* ego plans (world.py:102-104) */
         plan_one(d, ws, w_plan, d->check_plans ? oplans : NULL, plan, NULL, NULL, NULL, NULL);
-        if (ctrl) { ctrl[2 * i] = plan[0]; ctrl[2 * i + 1] = plan[1]; }
+        if (ctrl) { ctrl[2 * k] = plan[0]; ctrl[2 * k + 1] = plan[1]; }
         /* all cars step through the real dynamics (world.py:106-107) */
         float nxt[OCD_MAX_CARS * 4];
         {
@@ -519,9 +517,37 @@ static float episode(const ocd_scenario_desc *d, const float *init, const float 
                     &nxt[4 * (j + 1)], &nxt[4 * (j + 1) + 1], &nxt[4 * (j + 1) + 2], &nxt[4 * (j + 1) + 3], NULL);
         }
         memcpy(ws, nxt, sizeof(float) * C * 4);
-        if (traj) memcpy(traj + (size_t)(i + 1) * C * 4, ws, sizeof(float) * C * 4);
+        if (traj) memcpy(traj + (size_t)(k + 1) * C * 4, ws, sizeof(float) * C * 4);
     }
     return G;
+}
+
+/* one episode: world.reset() (every car back to its init_state, FixedPlanCar.t = 0), then T steps */
+static float episode(const ocd_scenario_desc *d, const float *init, const float *w_plan, int sample,
+                     float *traj, float *ctrl)
+{
+    float ws[OCD_MAX_CARS * 4];
+    memcpy(ws, init, 4 * sizeof(float));
+    for (int j = 0; j < d->n_cars - 1; ++j) memcpy(ws + 4 * (j + 1), d->other_init[j], 4 * sizeof(float));
+    return run_steps(d, ws, w_plan, sample, 0, d->episode_len, traj, ctrl);
+}
+
+int32_t ocd_rollout_from_state_cpu(const ocd_scenario_desc *d, const float *world_state,
+                                   const float *weights, int32_t weights_per_problem,
+                                   int32_t first_step, int32_t n_steps, int32_t sample,
+                                   float *returns_out, float *traj_out, float *ctrl_out, int64_t B)
+{
+    if (!check_desc(d) || !world_state || !returns_out || B < 0 || n_steps < 0) return OCD_ERR_INVALID_ARG;
+    const int C = d->n_cars, D = d->n_lanes + 4;
+    for (int64_t b = 0; b < B; ++b) {
+        float ws[OCD_MAX_CARS * 4];
+        memcpy(ws, world_state + b * C * 4, sizeof(float) * C * 4);
+        const float *w = weights ? (weights + (weights_per_problem ? b * D : 0)) : NULL;
+        returns_out[b] = run_steps(d, ws, w, sample, first_step, n_steps,
+                                   traj_out ? traj_out + b * (n_steps + 1) * C * 4 : NULL,
+                                   ctrl_out ? ctrl_out + b * n_steps * 2 : NULL);
+    }
+    return OCD_OK;
 }
 
 int32_t ocd_rollout_episodes_cpu(const ocd_scenario_desc *d, const float *init_states,

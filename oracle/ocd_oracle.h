@@ -67,6 +67,11 @@ int32_t ocd_rollout_episodes_cpu(const ocd_scenario_desc *d,
                                  float *returns_out, float *traj_out, float *ctrl_out,
                                  int32_t n_threads);
 
+int32_t ocd_rollout_from_state_cpu(const ocd_scenario_desc *d, const float *world_state,
+                                   const float *weights, int32_t weights_per_problem,
+                                   int32_t first_step, int32_t n_steps, int32_t sample,
+                                   float *returns_out, float *traj_out, float *ctrl_out, int64_t B);
+
 int32_t ocd_reward_batch_cpu(const ocd_scenario_desc *d,
                              const float *world_state, const float *weights,
                              float *feats_out, float *reward_out, int64_t B);

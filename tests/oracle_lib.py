@@ -54,6 +54,9 @@ class Oracle:
         lib.ocd_rollout_episodes_cpu.restype = C.c_int32
         lib.ocd_rollout_episodes_cpu.argtypes = [_D, _F, _F, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                                  _F, _F, _F, C.c_int32]
+        lib.ocd_rollout_from_state_cpu.restype = C.c_int32
+        lib.ocd_rollout_from_state_cpu.argtypes = [_D, _F, _F, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                                   _F, _F, _F, C.c_int64]
         lib.ocd_reward_batch_cpu.restype = C.c_int32
         lib.ocd_reward_batch_cpu.argtypes = [_D, _F, _F, _F, _F, C.c_int64]
         lib.ocd_oracle_uses_libm.restype = C.c_int32
@@ -143,6 +146,20 @@ class Oracle:
                                                _fp(ret), _fp(traj), _fp(ctrl), n_threads)
         if st != 0:
             raise RuntimeError(f"ocd_rollout_episodes_cpu -> {st}")
+        return dict(returns=ret, traj=traj, ctrl=ctrl)
+
+    def rollout_from_state(self, desc, world_state, weights, first_step, n_steps, sample=0):
+        ws = np.ascontiguousarray(world_state, dtype=np.float32).reshape(-1, desc.n_cars, 4)
+        B = ws.shape[0]
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float32)
+        per = int(w is not None and w.ndim == 2)
+        ret = np.zeros(B, dtype=np.float32)
+        traj = np.zeros((B, n_steps + 1, desc.n_cars, 4), dtype=np.float32)
+        ctrl = np.zeros((B, n_steps, 2), dtype=np.float32)
+        st = self.lib.ocd_rollout_from_state_cpu(C.byref(desc), _fp(ws), _fp(w), per, first_step, n_steps, sample,
+                                                 _fp(ret), _fp(traj), _fp(ctrl), B)
+        if st != 0:
+            raise RuntimeError(f"ocd_rollout_from_state_cpu -> {st}")
         return dict(returns=ret, traj=traj, ctrl=ctrl)
 
     def reward_batch(self, desc, world_state, weights):

@@ -1,0 +1,199 @@
+"""GPU: the reference-shaped API (interact_drive mirror) drives the HIP path and reproduces the oracle.
+
+The first tests are the reference's own planner / dynamics tests re-typed against the mirror
+(interact_drive/planner/tests/test_naivePlanner.py, interact_drive/tests/test_simulation_utils.py).
+"""
+import numpy as np
+import pytest
+
+from l4dc_mpc_ocd_amd import abi, scenarios, sharding
+from l4dc_mpc_ocd_amd.interact_drive import Tensor
+from l4dc_mpc_ocd_amd.interact_drive.car import FixedPlanCar, PlannerCar
+from l4dc_mpc_ocd_amd.interact_drive.experiments import replanning_world
+from l4dc_mpc_ocd_amd.interact_drive.planner import NaivePlanner
+from l4dc_mpc_ocd_amd.interact_drive.reward_design import MPC_ORD, evaluate_weights, finite_horizon_env
+from l4dc_mpc_ocd_amd.interact_drive.simulation_utils import batched_next_car_state, next_car_state
+from l4dc_mpc_ocd_amd.interact_drive.world import ThreeLaneCarWorld
+
+pytestmark = pytest.mark.gpu
+PI_2 = np.pi / 2
+
+
+class TargetSpeedPlannerCar(PlannerCar):
+    """interact_drive/planner/tests/targetSpeedRewardMaximizerCar.py:12-57 (reward -(v - target)^2)."""
+    _ocd_reward_kind = abi.OCD_REWARD_TARGET_SPEED
+
+    def __init__(self, env, init_state, horizon, target_speed, friction=0.2):
+        super().__init__(env, init_state, horizon, friction=friction)
+        self.target_speed = np.float32(target_speed)
+
+
+def same(a, b):
+    a = np.asarray(a, dtype=np.float32); b = np.asarray(b, dtype=np.float32)
+    return a.shape == b.shape and bool(np.all(a == b))
+
+
+# ---- the reference's planner tests, against the mirror ------------------------------------------
+def test_zero_friction_correct_speed(hip):
+    world = ThreeLaneCarWorld()
+    init_state = np.array([0., 0., 1., PI_2], dtype=np.float32)
+    car = TargetSpeedPlannerCar(world, init_state, 4, target_speed=1., friction=0.)
+    world.add_car(car)
+    planner = NaivePlanner(world, car, horizon=5, learning_rate=5.0, n_iter=100)
+    plan = planner.generate_plan([car.state])
+    assert len(plan) == 5
+    for i in range(len(plan)):
+        np.testing.assert_allclose(plan[i].numpy(), np.array([0., 0.]), atol=1e-5)
+
+
+def test_friction_correct_speed(hip):
+    friction = 0.5
+    world = ThreeLaneCarWorld()
+    car = TargetSpeedPlannerCar(world, np.array([0., 0., 1., PI_2], dtype=np.float32), 4, target_speed=1.,
+                                friction=friction)
+    world.add_car(car)
+    planner = NaivePlanner(world, car, horizon=3, learning_rate=5.0, n_iter=500)
+    plan = planner.generate_plan([car.state])
+    assert len(plan) == 3
+    for i in range(len(plan)):
+        np.testing.assert_allclose(plan[i].numpy(), np.array([friction * 1.0 ** 2, 0.]), atol=1e-5)
+
+
+def test_plan_vs_fixed_plan_car_runs(hip):
+    """TestPlanVsFixedPlanCar.test_no_interaction: other_controls = [placeholder, (H,2) plan]."""
+    car, world, _ = finite_horizon_env(horizon=3)
+    other_car = world.cars[1]
+    planner = NaivePlanner(world, car, horizon=3, learning_rate=0.1, n_iter=50)
+    other_plan = np.zeros((3, 2), dtype=np.float32)
+    plan = planner.generate_plan([car.state, other_car.state], other_controls=[Tensor(0.0), other_plan])
+    assert len(plan) == 3 and all(p.shape == (2,) for p in plan) and np.all(np.isfinite(np.stack(plan)))
+
+
+# ---- the reference's dynamics tests --------------------------------------------------------------
+@pytest.mark.parametrize("state,friction,expect", [
+    ((0., 0., 1., PI_2), 0.0, (0., 1., 1., PI_2)), ((0., 0., 1., PI_2), 1.0, (0., 0.5, 0., PI_2)),
+    ((0., 0., 1., PI_2), 0.5, (0., 0.75, 0.5, PI_2)), ((0., 0., 1., 0.), 0.5, (0.75, 0., 0.5, 0.)),
+])
+def test_next_car_state_kats(hip, oracle, state, friction, expect):
+    out = next_car_state(np.array(state), np.array([0., 0.]), dt=1., friction=friction)
+    for g, w in zip(out, expect):
+        assert round(float(g) - float(w), 7) == 0
+    assert same(out, oracle.dynamics_step(state, (0., 0.), 1.0, friction))
+
+
+def test_next_car_state_batched(hip, oracle):
+    state = np.array([[0., 0., 1., PI_2], [0., 0., 1., 0.]])
+    nxt = batched_next_car_state(state, np.array([[0., 0.], [0., 0.]]), dt=1., friction=0.5)
+    np.testing.assert_almost_equal(nxt[:, 0], [0., 0.75]); np.testing.assert_almost_equal(nxt[:, 1], [0.75, 0.])
+    np.testing.assert_almost_equal(nxt[:, 2], [0.5, 0.5]); np.testing.assert_almost_equal(nxt[:, 3], [PI_2, 0.])
+    rng = np.random.default_rng(0)
+    st = rng.uniform(-2, 2, (1000, 4)).astype(np.float32)
+    u = rng.uniform(-10, 6, (1000, 2)).astype(np.float32)
+    got = batched_next_car_state(st, u, dt=0.1, friction=0.2)
+    ref = np.stack([oracle.dynamics_step(s, c, 0.1, 0.2) for s, c in zip(st, u)])
+    assert same(got, ref)
+
+
+# ---- the object-by-object world loop equals the fused episode kernel and the oracle ---------------
+@pytest.mark.parametrize("which", ["finite_horizon", "replanning"])
+def test_world_step_loop_is_bitwise_the_episode(hip, oracle, which):
+    if which == "finite_horizon":
+        car, world, inits = finite_horizon_env(horizon=5, env_seeds=[7])
+        scn, T, S = scenarios.finite_horizon(horizon=5), 15, 1
+    else:
+        car, world, inits = replanning_world.setup_world(env_seeds=[7])
+        scn, T, S = scenarios.replanning(horizon=5), 20, 2
+    w = scn.candidate_weights(2, seed=9)[1]
+    w32 = scenarios.planner_weights_fp32(w)
+    ref = oracle.rollout(scn.desc, np.asarray(inits[0])[None], w32[None], want_traj=True)
+    designer = MPC_ORD(world, car, inits, T, num_samples=S).designer_weights
+    car.weights = w / np.linalg.norm(w) / np.linalg.norm(w / np.linalg.norm(w))     # mpc_ord.py:71,120 then the setter
+    assert same(car.weights, w32)
+    car.init_state = Tensor(inits[0])
+    for s in range(S):
+        world.reset()                                     # mpc_ord.py:89
+        total = np.float32(0)
+        states = [np.stack(world.state)]
+        ctrls = []
+        for i in range(T):
+            past_state, controls, state = world.step()    # mpc_ord.py:96
+            total = np.float32(total + car.reward_fn(past_state, controls[car.index], weights=designer))
+            states.append(np.stack(state)); ctrls.append(np.asarray(controls[car.index]))
+        assert same(np.stack(ctrls), ref["ctrl"][s]), f"controls, sample {s}"
+        assert same(np.stack(states), ref["traj"][s]), f"trajectory, sample {s}"
+        assert same(total, ref["returns"][s]), f"return, sample {s}"
+
+
+def test_rollout_from_state_bitwise(hip, oracle):
+    from l4dc_mpc_ocd_amd.engine import Engine
+    scn = scenarios.replanning(horizon=5)
+    eng = Engine(scn, "cuda:0")
+    inits = scn.init_dist.sample(2, seed=2)
+    w32 = np.stack([scenarios.planner_weights_fp32(c) for c in scn.candidate_weights(2, seed=3)])
+    full = oracle.rollout(scn.desc, inits, w32, want_traj=True)
+    # restart every episode of sample 1 from its state after 2 steps and run 5 more (crosses the teleport)
+    ws = full["traj"][1::2, 2]                       # episodes with s = 1: e = (p*N+n)*2 + 1
+    wts = np.repeat(w32, 2, axis=0)
+    got = eng.rollout_from_state(ws, wts, first_step=2, n_steps=5, sample=1)
+    ref = oracle.rollout_from_state(scn.desc, ws, wts, 2, 5, sample=1)
+    assert same(got["traj"], ref["traj"]) and same(got["ctrl"], ref["ctrl"]) and same(got["returns"], ref["returns"])
+    assert same(got["traj"], full["traj"][1::2, 2:8]) and same(got["ctrl"], full["ctrl"][1::2, 2:7])
+
+
+# ---- MPC_ORD ---------------------------------------------------------------------------------------
+def test_mpc_ord_eval_weights_matches_oracle_fitness(hip, oracle, tmp_path):
+    car, world, inits = replanning_world.setup_world(env_seeds=[1, 2, 3])
+    scn = scenarios.replanning(horizon=5)
+    ord_ = MPC_ORD(world, car, inits, 20, num_samples=2, save_path=str(tmp_path / "hist.pkl"))
+    cands = scn.candidate_weights(3, seed=11)
+    w32 = np.stack([scenarios.planner_weights_fp32(c) for c in cands])
+    ref_ret = oracle.rollout(scn.desc, np.asarray(inits), w32)["returns"]
+    ref_cost = sharding.fitness_from_returns(ref_ret, 3, 3, 2)
+    cost = ord_.eval_population(cands)
+    assert np.array_equal(cost, ref_cost)
+    c1 = ord_.eval_weights(list(cands[1]))                       # scalar signature of the reference
+    assert c1 == ref_cost[1]
+    assert len(ord_.history) == 4 and ord_.history[1][1] == -ref_cost[1] and ord_.iter == 4
+    r = ord_.eval_weights_for_init(inits[2], cands[2][None], render=False)
+    assert r == np.float32(ref_ret.reshape(3, 3, 2)[2, 2, 0] + ref_ret.reshape(3, 3, 2)[2, 2, 1])
+    assert world.unlucky_car_idx == 2                           # an even number of resets later
+
+
+def test_evaluate_weights_helper(hip, oracle):
+    car, world, inits = finite_horizon_env(horizon=5, env_seeds=[4])
+    scn = scenarios.finite_horizon(horizon=5)
+    agent = scn.tuned_weights
+    got = evaluate_weights(car, agent, world, horizon=15)
+    w32 = (agent / np.linalg.norm(agent)).astype(np.float32)
+    d = scenarios.finite_horizon(horizon=5).desc
+    for i, v in enumerate(w32):
+        d.designer_weights[i] = v                                # the helper scores with the agent weights
+    ref = oracle.rollout(d, np.asarray(inits[0], dtype=np.float32)[None], w32[None])["returns"][0]
+    assert same(got, ref)
+
+
+def test_cmaes_and_random_search_drivers(hip, tmp_path):
+    car, world, inits = finite_horizon_env(horizon=5, env_seeds=[1, 2])
+    ord_ = MPC_ORD(world, car, inits, 15, save_path=str(tmp_path / "cma.pkl"))
+    best = ord_.optimize_cmaes(seed=3, sigma0=0.05, maxiter=2)
+    assert best.shape == (7,) and len(ord_.history) == 1 + 2 * 9 and ord_.done
+    assert len(ord_.generation_seconds) == 2
+    import pickle
+    with open(tmp_path / "cma.pkl", "rb") as f:
+        hist = pickle.load(f)
+    assert len(hist) == 19 and hist.seed == 3
+    ord2 = MPC_ORD(world, car, inits, 15)
+    top = ord2.optimize_random_search(n_iter=6, seed=5)
+    np.random.seed(5)
+    first = np.random.rand(7) * 2 - 1
+    assert np.allclose(ord2.history[1][0], first / np.linalg.norm(first)) and len(ord2.history) == 7
+    assert top[1] == max(h[1] for h in ord2.history)
+
+
+def test_reward_fn_and_features_match_oracle(hip, oracle):
+    car, world, inits = finite_horizon_env(horizon=5, env_seeds=[4])
+    scn = scenarios.finite_horizon(horizon=5)
+    state = [Tensor([0.12, -0.62, 0.7, 1.5]), Tensor([0.1, -0.6, 0.5, PI_2])]
+    r_ref, f_ref, _ = oracle.reward(scn.desc, np.stack(state), car.weights)
+    assert same(car.reward_fn(state, None), r_ref) and same(car.features(state, None), f_ref)
+    assert f_ref[5] > 0 and f_ref[6] > 0                      # collision and fence features are live here

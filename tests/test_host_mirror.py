@@ -1,0 +1,143 @@
+"""Host-side mirror of the reference API (l4dc_mpc_ocd_amd.interact_drive): CPU-checkable parts.
+
+Descriptor construction from the object graph, argument validation with the reference's error
+behaviour, the numpy Tensor stand-in, the CMA-ES driver, fitness reduction types.
+"""
+import pickle
+
+import numpy as np
+import pytest
+
+from l4dc_mpc_ocd_amd import abi, scenarios, sharding
+from l4dc_mpc_ocd_amd.interact_drive import Tensor, simulation_utils
+from l4dc_mpc_ocd_amd.interact_drive._describe import describe
+from l4dc_mpc_ocd_amd.interact_drive.car import FixedPlanCar, FixedVelocityCar, PlannerCar
+from l4dc_mpc_ocd_amd.interact_drive.experiments import local_opt_scenario, merging, replanning_world
+from l4dc_mpc_ocd_amd.interact_drive.planner import NaivePlanner
+from l4dc_mpc_ocd_amd.interact_drive.reward_design import MPC_ORD, finite_horizon_env
+from l4dc_mpc_ocd_amd.interact_drive.reward_design.cmaes import CMAES
+from l4dc_mpc_ocd_amd.interact_drive.world import ThreeLaneCarWorld, TwoLaneCarWorld
+
+
+def _mpc_desc(car, world, inits, T, S=1):
+    m = MPC_ORD(world, car, inits, T, num_samples=S)
+    pa = car.planner_args
+    return describe(world, car, car.horizon, pa.get("learning_rate", 0.1), pa.get("n_iter", 100),
+                    pa.get("extra_inits", False), episode_len=T, n_samples=S, designer_weights=m.designer_weights)
+
+
+def test_factories_build_the_same_descriptors_as_scenarios_py():
+    car, world, inits = finite_horizon_env(horizon=5, env_seeds=[1, 2])
+    assert bytes(_mpc_desc(car, world, inits, 15)) == bytes(scenarios.finite_horizon(horizon=5).desc)
+    car, world, inits = finite_horizon_env(horizon=6, env_seeds=[1], extra_inits=True)
+    assert bytes(_mpc_desc(car, world, inits, 15)) == bytes(scenarios.finite_horizon(horizon=6, extra_inits=True).desc)
+    car, world, inits = local_opt_scenario.local_opt_env(env_seeds=[3], extra_inits=True)
+    assert bytes(_mpc_desc(car, world, inits, 15)) == bytes(scenarios.local_opt(horizon=5, extra_inits=True).desc)
+    car, world, inits = replanning_world.setup_world(env_seeds=[1])
+    assert bytes(_mpc_desc(car, world, inits, 20, S=2)) == bytes(scenarios.replanning(horizon=5).desc)
+    car, o1, o2, world = merging.setup_world()
+    assert bytes(_mpc_desc(car, world, [car.init_state], 15)) == bytes(scenarios.merging(horizon=5).desc)
+
+
+def test_lanes_and_world_bookkeeping():
+    w3, w2 = ThreeLaneCarWorld(), TwoLaneCarWorld()
+    assert [float(l.p[0]) for l in w3.lanes] == pytest.approx([-0.1, 0.0, 0.1])
+    assert [float(l.p[0]) for l in w2.lanes] == pytest.approx([-0.05, 0.05])
+    assert all(tuple(l.n) == (-1.0, 0.0) for l in w3.lanes)
+    assert float(w3.lanes[0].dist2median((0.0, 3.0))) == pytest.approx(0.01)
+    car, world, _ = replanning_world.setup_world(env_seeds=[1])
+    assert world.unlucky_car_idx == 2 and world._teleport_cars() == [1, 2, 1, 2]   # after setup's one reset()
+    assert [c.index for c in world.cars] == [0, 1, 2]
+    assert world.cars[1].control_already_determined_for_current_step
+
+
+def test_tensor_stand_in():
+    t = Tensor([1.0, 2.0])
+    assert t.dtype == np.float32 and t.shape == (2,) and isinstance(t.numpy(), np.ndarray)
+    assert float(t[0]) == 1.0
+    t.assign([3.0, 4.0])
+    assert t.tolist() == [3.0, 4.0]
+    assert Tensor(2.5).numpy() == np.float32(2.5)
+
+
+def test_argument_validation_matches_the_reference():
+    # interact_drive/tests/test_simulation_utils.py:99-110: wrong shapes raise ValueError before any device work
+    with pytest.raises(ValueError):
+        simulation_utils.next_car_state(state=[0., 0.], control=[0., 0.], dt=0.1)
+    with pytest.raises(ValueError):
+        simulation_utils.next_car_state(state=[0., 0., 1., np.pi / 2], control=[0., 0., 0.], dt=0.1)
+    with pytest.raises(ValueError):
+        simulation_utils.batched_next_car_state(np.zeros((3, 3)), np.zeros((3, 2)), 0.1)
+    car, world, _ = finite_horizon_env(horizon=5)
+    planner = NaivePlanner(world, car, 5)
+    with pytest.raises(NotImplementedError):
+        planner.generate_plan(use_lbfgs=True)
+    with pytest.raises(NotImplementedError):
+        NaivePlanner(world, car, 5, leaf_evaluation=lambda s, c: 0)
+    with pytest.raises(ValueError):
+        planner._other_plans([None, np.zeros((4, 2))])               # wrong horizon
+    with pytest.raises(ValueError):
+        planner._world_state([np.zeros(4)])                         # one state for a two-car world
+
+
+def test_unsupported_worlds_fail_loudly():
+    world = ThreeLaneCarWorld()
+    plain = PlannerCar(world, np.array([0., 0., 1., np.pi / 2]), horizon=5)
+    world.add_car(plain)
+    with pytest.raises(NotImplementedError):                       # arbitrary Python reward_fn is not compiled
+        describe(world, plain, 5)
+    world = ThreeLaneCarWorld()
+    other = FixedVelocityCar(world, np.array([0, -0.6, 0.5, np.pi / 2]))
+    car = merging.ThreeLaneTestCar(world, np.array([0., 0., 1., np.pi / 2]), horizon=5, weights=np.ones(7))
+    world.add_cars([other, car])
+    with pytest.raises(NotImplementedError):                       # planning car must be car 0
+        describe(world, car, 5)
+
+
+def test_other_plans_gather_reads_from_index_zero():
+    """planner_car.py:66-75 quirk: plan[j] for j < len(plan) else default_control, at every step."""
+    car, world, _ = replanning_world.setup_world(env_seeds=[1])
+    d = describe(world, car, 6)
+    scn = scenarios.Scenario("x", d, None, None)
+    op = scn.other_plans()
+    assert op.shape == (2, 6, 2)
+    np.testing.assert_allclose(op[0, :, 1], [0, 2.7, 0, -2.7, 0, 0], rtol=1e-6)
+    np.testing.assert_allclose(op[1, :, 1], [0, -2.7, 0, 2.7, 0, 0], rtol=1e-6)
+    np.testing.assert_allclose(op[0, :, 0], [0, 0.7, 0, 0, 0, 0], rtol=1e-6)
+
+
+def test_fitness_accumulation_types():
+    # samples summed in fp32, inits in float64, / S, negated (mpc_ord.py:102,126-151)
+    r = np.array([[[1e-8, 1.0], [3.0, 4.0]], [[0.5, 0.25], [1.0, 2.0]]], dtype=np.float32)
+    cost = sharding.fitness_from_returns(r.reshape(-1), 2, 2, 2)
+    assert cost.dtype == np.float64
+    exp0 = -(float(np.float32(np.float32(1e-8) + np.float32(1.0))) + float(np.float32(7.0))) / 2
+    assert cost[0] == exp0 and cost[1] == -(0.75 + 3.0) / 2
+
+
+def test_planner_weight_normalisation_chain():
+    w = np.array([-5, 0., 0., 0., -6., -50, -50])
+    w32 = scenarios.planner_weights_fp32(w)
+    assert w32.dtype == np.float32 and abs(np.linalg.norm(w32) - 1) < 1e-6
+    assert np.array_equal(scenarios.planner_weights_fp32(w[None]), w32)      # (1, D) input, mpc_ord.py:69-70
+
+
+def test_cmaes_minimises_a_quadratic():
+    es = CMAES([1.0] * 7, 0.3, seed=3)
+    assert es.lam == 4 + int(3 * np.log(7)) == 9                               # pycma's default popsize for n=7
+    for _ in range(150):
+        X = es.ask()
+        es.tell(X, np.sum((X - 0.25) ** 2, axis=1))
+    assert es.best_f < 1e-8 and np.allclose(es.mean, 0.25, atol=1e-3)
+
+
+def test_history_pickle_format(tmp_path):
+    h = __import__("l4dc_mpc_ocd_amd.interact_drive.reward_design.mpc_ord", fromlist=["list2"]).list2()
+    h.seed = 5
+    h.append((np.ones(3), -1.5))
+    p = tmp_path / "h.pkl"
+    with open(p, "wb") as f:
+        pickle.dump(h, f)
+    with open(p, "rb") as f:
+        g = pickle.load(f)
+    assert g[0][1] == -1.5 and list(g[0][0]) == [1, 1, 1]
