@@ -1,0 +1,85 @@
+"""The C-ABI library loads on a machine without a GPU, exports every symbol include/ocd.h declares,
+its struct layout matches the ctypes mirror, and compute entry points fail loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from l4dc_mpc_ocd_amd import abi, scenarios
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "ocd.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ocd_[a-z_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    lib = abi.load_hip_library()
+    names = declared_functions()
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/ocd.h but not exported by libocd_hip.so"
+    assert sorted(n for n, _, _ in abi.HIP_SYMBOLS) == names       # the Python binding covers the whole header
+    assert lib.ocd_abi_version() == abi.OCD_ABI_VERSION
+
+
+def test_struct_layout_matches_the_header(tmp_path):
+    fields = [f for f, _ in abi.ScenarioDesc._fields_]
+    prog = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void){',
+            'printf("%zu\\n", sizeof(ocd_scenario_desc));']
+    prog += [f'printf("%zu\\n", offsetof(ocd_scenario_desc, {f}));' for f in fields]
+    prog += ['return 0;}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(prog))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", str(src), "-o", str(exe)], check=True)
+    out = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert out[0] == C.sizeof(abi.ScenarioDesc)
+    assert out[1:] == [getattr(abi.ScenarioDesc, f).offset for f in fields]
+
+
+@pytest.mark.skipif(__import__("torch").cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_no_gpu_means_error_not_fallback():
+    lib = abi.load_hip_library()
+    scn = scenarios.finite_horizon(horizon=5)
+    h = C.c_void_p()
+    assert lib.ocd_scenario_create(C.byref(scn.desc), C.byref(h)) == abi.OCD_OK     # validation is host-only
+    ret = np.zeros(3, dtype=np.float32)
+    st = lib.ocd_rollout_episodes(h, ret.ctypes.data, ret.ctypes.data, 1, 3, 0, 3, ret.ctypes.data, None, None, None)
+    assert st == abi.OCD_ERR_NO_DEVICE and b"no CPU fallback" in lib.ocd_last_error()
+    st = lib.ocd_plan_batch(h, ret.ctypes.data, ret.ctypes.data, 0, None, ret.ctypes.data, None, None, None, None, 1, None)
+    assert st == abi.OCD_ERR_NO_DEVICE
+    lib.ocd_scenario_destroy(h)
+    from l4dc_mpc_ocd_amd.engine import Engine
+    with pytest.raises(RuntimeError):
+        Engine(scn)
+
+
+def test_descriptor_validation_messages():
+    lib = abi.load_hip_library()
+    h = C.c_void_p()
+    for field, value, word in [("horizon", 99, b"horizon"), ("n_samples", 0, b"n_samples"), ("abi_version", 7, b"abi_version"),
+                               ("n_lanes", 0, b"lane")]:
+        d = scenarios.finite_horizon(horizon=5).desc
+        setattr(d, field, value)
+        assert lib.ocd_scenario_create(C.byref(d), C.byref(h)) == abi.OCD_ERR_INVALID_ARG
+        assert word in lib.ocd_last_error()
+    assert lib.ocd_scenario_create(None, C.byref(h)) == abi.OCD_ERR_INVALID_ARG
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is a checker: nothing under the package or the C sources may reference oracle/."""
+    pkg = os.path.join(ROOT, "l4dc-mpc-ocd_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle_lib" not in text and "libocd_oracle" not in text and "ocd_refmath" not in text, f
