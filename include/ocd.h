@@ -116,6 +116,10 @@ int32_t ocd_device_count(void);
 /* Thread-local description of the last error returned on this thread. */
 const char *ocd_last_error(void);
 
+/* Process-wide tuning knobs; results never depend on them.
+ *   "segs_per_wave": trajectories packed into one wavefront (1..64/H), 0 = automatic. */
+int32_t ocd_set_option(const char *name, int32_t value);
+
 /* Validate a descriptor and build the handle the kernels read their constants
  * from.  Replaces the reference's scenario factories + NaivePlanner.__init__
  * (naive_planner.py:19-30, planner_car.py:49-52). */

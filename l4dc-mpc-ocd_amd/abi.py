@@ -84,6 +84,7 @@ HIP_SYMBOLS = [
     ("ocd_abi_version", C.c_int32, []),
     ("ocd_device_count", C.c_int32, []),
     ("ocd_last_error", C.c_char_p, []),
+    ("ocd_set_option", C.c_int32, [C.c_char_p, C.c_int32]),
     ("ocd_scenario_create", C.c_int32, [C.POINTER(ScenarioDesc), C.POINTER(_VP)]),
     ("ocd_scenario_destroy", None, [_VP]),
     ("ocd_plan_batch", C.c_int32,

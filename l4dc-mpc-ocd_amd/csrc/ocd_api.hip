@@ -28,9 +28,12 @@ struct ocd_scenario {
     float *dev_plans[OCD_MAX_DEVICES];
 };
 
+#include <atomic>
+
 namespace {
 
 thread_local char g_err[512] = "";
+std::atomic<int32_t> g_opt_segs{0};        // "segs_per_wave": 0 = automatic
 
 int32_t fail(int32_t status, const char *fmt, ...)
 {
@@ -69,6 +72,8 @@ int32_t validate(const ocd_scenario_desc *d)
             if (d->teleport_car[s] >= d->n_cars)
                 return fail(OCD_ERR_INVALID_ARG, "teleport_car[%d] = %d >= n_cars", s, d->teleport_car[s]);
     if (!(d->dt > 0.0f)) return fail(OCD_ERR_INVALID_ARG, "dt must be > 0");
+    if (d->reward_kind == OCD_REWARD_LANE_FEATURES && !(d->fence_lo >= 0.0f && d->fence_width > 0.0f))
+        return fail(OCD_ERR_INVALID_ARG, "fence_lo must be >= 0 and fence_width > 0 (0.05*num_lanes - 0.05, 0.05)");
     return OCD_OK;
 }
 
@@ -89,6 +94,7 @@ void base_params(const ocd_scenario *scn, ocd::KernelParams &p)
     p.d = scn->desc;
     p.K = scn->K;
     p.S = scn->desc.n_samples;
+    p.segs_used = g_opt_segs.load();
 }
 
 int32_t launch(const ocd_scenario *scn, const ocd::KernelParams &p, void *hip_stream)
@@ -117,6 +123,17 @@ int32_t ocd_device_count(void)
 }
 
 const char *ocd_last_error(void) { return g_err; }
+
+int32_t ocd_set_option(const char *name, int32_t value)
+{
+    if (!name) return fail(OCD_ERR_INVALID_ARG, "option name is NULL");
+    if (std::strcmp(name, "segs_per_wave") == 0) {
+        if (value < 0 || value > 64) return fail(OCD_ERR_INVALID_ARG, "segs_per_wave %d out of [0,64]", value);
+        g_opt_segs.store(value);
+        return OCD_OK;
+    }
+    return fail(OCD_ERR_INVALID_ARG, "unknown option '%s'", name);
+}
 
 int32_t ocd_scenario_create(const ocd_scenario_desc *desc, ocd_scenario **out)
 {

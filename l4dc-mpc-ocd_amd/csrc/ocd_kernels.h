@@ -35,6 +35,7 @@ struct KernelParams {
     int32_t t0;                // world step index of the first control step (scripted plans, teleport)
     int32_t from_state;        // ROLLOUT: 1 = every problem starts from its own world_state [B,C,4]
     int32_t sample_fixed;      // from_state: which world.reset() outcome (teleported car) applies
+    int32_t segs_used;         // trajectories per wavefront (<= 64/H); 0 = let the launcher choose
 };
 
 // (horizon, scripted cars) pairs with a compiled kernel.  Horizons 5/6: the

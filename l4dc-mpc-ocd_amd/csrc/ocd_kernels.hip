@@ -160,14 +160,42 @@ __device__ __forceinline__ BumpGeom bump_geom(float ox, float oy, float hx, floa
 
 struct Q4 { float qx, qy, qv, qth; };
 
+// Conservative per-lane tests for the wave-uniform skips of reward_state.
+//  fence:  _f(x - lo) and _f(-x - lo) are both 0 (value AND gradient, math_utils.py:28-31) unless one
+//          argument is > 0; then S = 0/den = 0, the feature is 0*|x| and every adjoint term is +-0.
+//  collision: bump_x*bump_y and its gradients are +-0 unless x_norm^2 < 1 AND y_norm^2 < 1
+//          (math_utils.py:171-178); |z - c| < 1.001*w is a cheap superset of (z-c)/w squared < 1.
+__device__ __forceinline__ bool needs_fence(const ocd_scenario_desc &d, float x)
+{
+    return ((x - d.fence_lo) > 0.0f) || (((-x) - d.fence_lo) > 0.0f);
+}
+
+template <int NO>
+__device__ __forceinline__ bool needs_collision(float x, float y, const BumpGeom (&bg)[NO > 0 ? NO : 1])
+{
+    bool need = false;
+#pragma unroll
+    for (int j = 0; j < NO; ++j) {
+        const float dx = x - bg[j].cx, dy = y - bg[j].cy;
+        const bool nx = ((dx < 0.0f) ? -dx : dx) < bg[j].wx * 1.001f;
+        const bool ny = ((dy < 0.0f) ? -dy : dy) < bg[j].wy * 1.001f;
+        need = need || (nx && ny);
+    }
+    return need;
+}
+
 // reward of one world state and (GRAD) its gradient w.r.t. the ego state
 // (merging.py:44-83, linear_reward_car.py:49-55, targetSpeedRewardMaximizerCar.py:50-56)
 template <int NO, bool GRAD>
 __device__ __forceinline__ float reward_state(const ocd_scenario_desc &d, const float (&w)[OCD_MAX_FEATURES],
                                               float x, float y, float v, float sn, float cn,
                                               const BumpGeom (&bg)[NO > 0 ? NO : 1], Q4 &q,
-                                              float *feats /* nullptr or [D] global */)
+                                              float *feats /* nullptr or [D] global */,
+                                              const bool do_col = true, const bool do_fence = true)
 {
+    // do_col / do_fence are WAVE-UNIFORM: false only when the caller has proved that, for every live
+    // lane, the collision bumps / the fence thresholds are identically zero together with their
+    // gradients (see needs_collision / needs_fence), so skipping them changes no bit of any result.
     if (d.reward_kind == OCD_REWARD_TARGET_SPEED) {
         const float dv = v - d.target_speed;
         const float sq = dv * dv;
@@ -204,23 +232,33 @@ __device__ __forceinline__ float reward_state(const ocd_scenario_desc &d, const 
     BumpTape bx[NO > 0 ? NO : 1], by[NO > 0 ? NO : 1];
     float bxv[NO > 0 ? NO : 1], byv[NO > 0 ? NO : 1], col[NO > 0 ? NO : 1];
     float pcol = 0.0f;
+    int ntie_col = NO;
+    if (do_col) {
 #pragma unroll
-    for (int j = 0; j < NO; ++j) {
-        bxv[j] = bump_fwd(x, bg[j].cx, bg[j].wx, bx[j]);
-        byv[j] = bump_fwd(y, bg[j].cy, bg[j].wy, by[j]);
-        col[j] = bxv[j] * byv[j];
-        pcol = (j == 0) ? col[0] : max_tf(pcol, col[j]);
+        for (int j = 0; j < NO; ++j) {
+            bxv[j] = bump_fwd(x, bg[j].cx, bg[j].wx, bx[j]);
+            byv[j] = bump_fwd(y, bg[j].cy, bg[j].wy, by[j]);
+            col[j] = bxv[j] * byv[j];
+            pcol = (j == 0) ? col[0] : max_tf(pcol, col[j]);
+        }
+        ntie_col = 0;
+#pragma unroll
+        for (int j = 0; j < NO; ++j) ntie_col += (col[j] == pcol) ? 1 : 0;
     }
-    int ntie_col = 0;
-#pragma unroll
-    for (int j = 0; j < NO; ++j) ntie_col += (col[j] == pcol) ? 1 : 0;
 
-    ThrTape tp_p, tp_m;
-    const float Sp = thr_fwd(x, d.fence_lo, d.fence_width, d.fence_shape, tp_p);
-    const float Sm = thr_fwd(-x, d.fence_lo, d.fence_width, d.fence_shape, tp_m);
-    const float Ssum = Sp + Sm;
-    const float ax = (x < 0.0f) ? -x : x;
-    const float pf = Ssum * ax;
+    // fences = (S(x) + S(-x)) * |x| (merging.py:80-81).  With threshold - width = fence_lo >= 0 the two
+    // arguments x - lo and -x - lo cannot both be positive, and a side whose argument is <= 0 has
+    // F1 = 0 exactly: S = 0/den = 0 and every adjoint term of that side is +-0 (see needs_fence).  So
+    // one smooth_threshold evaluation on the possibly-active side gives S(x) + S(-x) and its gradient
+    // bit for bit (x + 0 = x), at half the divisions and exponentials.
+    ThrTape tp_f;
+    const bool side_p = (x - d.fence_lo) > 0.0f;
+    float Ssum = 0.0f, ax = 0.0f, pf = 0.0f;
+    if (do_fence) {
+        Ssum = thr_fwd(side_p ? x : -x, d.fence_lo, d.fence_width, d.fence_shape, tp_f);
+        ax = (x < 0.0f) ? -x : x;
+        pf = Ssum * ax;
+    }
 
     // reduce_sum(weights * feats), left to right over [phi0, lanes..., min, collision, fences]
     float r = w[0] * phi[0];
@@ -235,8 +273,8 @@ __device__ __forceinline__ float reward_state(const ocd_scenario_desc &d, const 
         w_f = (k == L + 3) ? w[k] : w_f;
     }
     r = r + w_min * pmin;
-    r = r + w_col * pcol;
-    r = r + w_f * pf;
+    if (do_col) r = r + w_col * pcol;      // skipped terms are exactly +-0
+    if (do_fence) r = r + w_f * pf;
     if (feats) {
         feats[0] = phi[0];
 #pragma unroll
@@ -263,7 +301,7 @@ __device__ __forceinline__ float reward_state(const ocd_scenario_desc &d, const 
             qx = qx + g_r * -1.0f;
         }
     }
-    if (NO > 0) {
+    if (NO > 0 && do_col) {
         const float col_share = w_col / (float)ntie_col;
 #pragma unroll
         for (int j = 0; j < NO; ++j) {
@@ -274,12 +312,14 @@ __device__ __forceinline__ float reward_state(const ocd_scenario_desc &d, const 
             qy = qy + bump_bwd(g_by, bg[j].wy, by[j]);
         }
     }
-    const float g_Ssum = w_f * ax;
-    const float g_ax = w_f * Ssum;
-    qx = qx + thr_bwd(g_Ssum, d.fence_shape, tp_p);
-    qx = qx + (-thr_bwd(g_Ssum, d.fence_shape, tp_m));
-    const float sgn = (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f);
-    qx = qx + g_ax * sgn;
+    if (do_fence) {
+        const float g_Ssum = w_f * ax;
+        const float g_ax = w_f * Ssum;
+        const float g_z = thr_bwd(g_Ssum, d.fence_shape, tp_f);
+        qx = qx + (side_p ? g_z : -g_z);
+        const float sgn = (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f);
+        qx = qx + g_ax * sgn;
+    }
     q.qx = qx; q.qy = qy;
     return r;
 }
@@ -330,8 +370,10 @@ mpc_kernel(const KernelParams p)
     const int slot = seg * HP + t;
     const int rowb = seg * HP;
 
-    const long long prob_raw = (long long)blockIdx.x * SEGS + seg;
-    const bool live = (seg < SEGS) && (prob_raw < p.n_problems);
+    // segs_used <= SEGS trajectories per wavefront: small batches are spread over more wavefronts
+    // (one trajectory each) so that the uniform feature skips act per trajectory; big batches pack.
+    const long long prob_raw = (long long)blockIdx.x * p.segs_used + seg;
+    const bool live = (seg < p.segs_used) && (prob_raw < p.n_problems);
     const long long prob = live ? prob_raw : (p.n_problems - 1);     // parked lanes shadow a real problem
 
     const float dt = d.dt, dt2 = d.dt_sq, fr = d.ego_friction, lr = d.learning_rate;
@@ -520,9 +562,12 @@ mpc_kernel(const KernelParams p)
             const float yn = y + sd;
 
             Q4 q;
+            const bool lane_feats = d.reward_kind == OCD_REWARD_LANE_FEATURES;
+            const bool do_fence = lane_feats && (__ballot(live && needs_fence(d, xn)) != 0ull);
+            const bool do_col = lane_feats && (NO > 0) && (__ballot(live && needs_collision<NO>(xn, yn, bg)) != 0ull);
             if (it == n_iter) {
                 // ===== last pass: objective only (naive_planner.py:154) =====
-                const float r = reward_state<NO, false>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr);
+                const float r = reward_state<NO, false>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, do_col, do_fence);
                 __builtin_amdgcn_wave_barrier();
                 xch[4 * SEGP + slot] = r;
                 __builtin_amdgcn_wave_barrier();
@@ -534,7 +579,7 @@ mpc_kernel(const KernelParams p)
                 loss = -Rsum;
                 break;
             }
-            reward_state<NO, true>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr);
+            reward_state<NO, true>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, do_col, do_fence);
 
             // ===== backward =====
             __builtin_amdgcn_wave_barrier();
@@ -734,7 +779,7 @@ static hipError_t launch_mpc(const KernelParams &p, hipStream_t st)
 {
     using G = Geo<H>;
     const int K = p.K;
-    const long long blocks = (p.n_problems + G::SEGS - 1) / G::SEGS;
+    const long long blocks = (p.n_problems + p.segs_used - 1) / p.segs_used;
     const size_t lds = ((size_t)K * G::NARR * G::SEGP + (size_t)2 * K * (G::SEGS + 1) * 4) * sizeof(float);
     hipLaunchKernelGGL((mpc_kernel<H, NO>), dim3((unsigned)blocks), dim3(64 * K), lds, st, p);
     return hipGetLastError();
@@ -742,8 +787,25 @@ static hipError_t launch_mpc(const KernelParams &p, hipStream_t st)
 
 #define OCD_CASE(HH, NN) if (H == HH && NO == NN) return launch_mpc<HH, NN>(p, st);
 
-hipError_t launch_mpc_dispatch(int H, int NO, const KernelParams &p, hipStream_t st, bool *supported)
+// Trajectories per wavefront for a launch of n problems: one per wavefront while that still leaves
+// SIMDs idle (256 CUs x 4 SIMDs), which keeps the uniform feature skips per trajectory; beyond that,
+// pack (up to 64/H) so that the number of wavefronts per SIMD stays minimal.
+int choose_segs(int H, long long n_problems, int K)
 {
+    const int segs_max = 64 / H;
+    const long long waves_unpacked = n_problems * K;
+    const long long budget = 256LL * 4;     // measured (config 3): fewest wavefronts per SIMD wins once every SIMD has one
+    long long segs = (waves_unpacked + budget - 1) / budget;
+    if (segs < 1) segs = 1;
+    if (segs > segs_max) segs = segs_max;
+    return (int)segs;
+}
+
+hipError_t launch_mpc_dispatch(int H, int NO, const KernelParams &p_in, hipStream_t st, bool *supported)
+{
+    KernelParams p = p_in;
+    if (p.segs_used <= 0) p.segs_used = choose_segs(H, p.n_problems, p.K);
+    if (p.segs_used > 64 / H) p.segs_used = 64 / H;
     *supported = true;
     OCD_KERNEL_TABLE(OCD_CASE)
     *supported = false;

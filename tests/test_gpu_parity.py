@@ -155,6 +155,28 @@ def test_rollout_bitwise(oracle, eng_factory, name, H, P, N):
     assert out["returns"].shape == (P * N * scn.desc.n_samples,)
 
 
+@pytest.mark.parametrize("segs", [1, 2, 6, 0])
+def test_results_do_not_depend_on_packing(oracle, eng_factory, hip, segs):
+    """segs_per_wave (trajectories per wavefront) is a pure performance knob: packed lanes, parked
+    lanes and the wave-uniform feature skips must not change a bit."""
+    scn = scenarios.finite_horizon(horizon=10, n_iter=40)
+    eng = eng_factory(scn)
+    ws = _world_states(scn, 29, seed=77)
+    w = np.stack([scenarios.planner_weights_fp32(c) for c in scn.candidate_weights(29, seed=78)])
+    ref = oracle.plan_batch(scn.desc, ws, w)
+    assert hip.ocd_set_option(b"segs_per_wave", segs) == 0
+    try:
+        out = eng.plan_batch(ws, w, want_all=True)
+        inits = scn.init_dist.sample(5, seed=79)
+        ro = eng.rollout(inits, w[:2], want_traj=True)
+    finally:
+        hip.ocd_set_option(b"segs_per_wave", 0)
+    assert_bitwise(out["all_plans"], ref["all_plans"]); assert_bitwise(out["all_losses"], ref["all_losses"])
+    rr = oracle.rollout(scn.desc, inits, w[:2], want_traj=True)
+    assert_bitwise(ro["traj"], rr["traj"]); assert_bitwise(ro["returns"], rr["returns"])
+    assert hip.ocd_set_option(b"nonsense", 1) != 0
+
+
 def test_rollout_episode_range_matches_full(oracle, eng_factory):
     """Sharding contract: any [ep_begin, ep_end) slice equals the same slice of the full run."""
     scn = scenarios.replanning(horizon=5)

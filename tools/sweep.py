@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Kernel-time sweep on the GPU box: ms per launch of the episode kernel for BASELINE configs and
+packing choices.  usage: python tools/sweep.py [--configs 2,3] [--segs 0,1,2,6] [--reps 5]"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", default="2")
+    ap.add_argument("--segs", default="0")
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--pop-scale", type=int, default=1, help="multiply the population (bigger batches)")
+    a = ap.parse_args()
+    import torch
+    from l4dc_mpc_ocd_amd import scenarios
+    from l4dc_mpc_ocd_amd.engine import Engine
+    for cfg in [int(c) for c in a.configs.split(",")]:
+        c = scenarios.BASELINE_CONFIGS[cfg]
+        scn = scenarios.SCENARIOS[c["scenario"]](horizon=c["horizon"])
+        P, N, S = c["pop"] * a.pop_scale, c["n_inits"], scn.desc.n_samples
+        inits = scn.init_dist.sample(N, seed=1000 + cfg)
+        w32 = np.stack([scenarios.planner_weights_fp32(x) for x in scn.candidate_weights(P, seed=2000 + cfg)])
+        eng = Engine(scn, "cuda:0")
+        init_dev = torch.as_tensor(inits, dtype=torch.float32).cuda()
+        w_dev = torch.as_tensor(w32).cuda()
+        E = P * N * S
+        ret = torch.empty(E, dtype=torch.float32, device="cuda")
+        for segs in [int(s) for s in a.segs.split(",")]:
+            assert eng.lib.ocd_set_option(b"segs_per_wave", segs) == 0
+            eng.time_rollout(init_dev, w_dev, 0, E, ret, 1)
+            ms = eng.time_rollout(init_dev, w_dev, 0, E, ret, a.reps)
+            print(f"cfg{cfg} {c['scenario']} H={c['horizon']} E={E} segs={segs}: {ms:.3f} ms/launch "
+                  f"-> {E / ms * 1e3:.0f} episodes/s  checksum {float(ret.sum()):.6f}", flush=True)
+        eng.lib.ocd_set_option(b"segs_per_wave", 0)
+
+
+if __name__ == "__main__":
+    main()
