@@ -100,10 +100,11 @@ void base_params(const ocd_scenario *scn, ocd::KernelParams &p)
 int32_t launch(const ocd_scenario *scn, const ocd::KernelParams &p, void *hip_stream)
 {
     bool supported = false;
-    hipError_t e = ocd::launch_mpc_dispatch(scn->desc.horizon, scn->desc.n_cars - 1, p, (hipStream_t)hip_stream, &supported);
+    const int L = scn->desc.reward_kind == OCD_REWARD_LANE_FEATURES ? scn->desc.n_lanes : 0;
+    hipError_t e = ocd::launch_mpc_dispatch(scn->desc.horizon, scn->desc.n_cars - 1, L, p, (hipStream_t)hip_stream, &supported);
     if (!supported)
-        return fail(OCD_ERR_UNSUPPORTED, "no compiled kernel for horizon %d with %d scripted cars (see OCD_KERNEL_TABLE)",
-                    scn->desc.horizon, scn->desc.n_cars - 1);
+        return fail(OCD_ERR_UNSUPPORTED, "no compiled kernel for horizon %d with %d scripted cars and %d lanes (see OCD_KERNEL_TABLE)",
+                    scn->desc.horizon, scn->desc.n_cars - 1, L);
     if (e != hipSuccess) return hip_fail(e, "mpc_kernel launch");
     return OCD_OK;
 }
@@ -341,8 +342,9 @@ int32_t ocd_reward_batch(const ocd_scenario *scn, const float *world_state, cons
     p.weights = weights;
     p.n_problems = B;
     bool supported = false;
-    hipError_t e = ocd::launch_reward(scn->desc.n_cars - 1, p, feats_out, reward_out, (hipStream_t)hip_stream, &supported);
-    if (!supported) return fail(OCD_ERR_UNSUPPORTED, "reward kernel: %d scripted cars", scn->desc.n_cars - 1);
+    const int L = scn->desc.reward_kind == OCD_REWARD_LANE_FEATURES ? scn->desc.n_lanes : 0;
+    hipError_t e = ocd::launch_reward(scn->desc.n_cars - 1, L, p, feats_out, reward_out, (hipStream_t)hip_stream, &supported);
+    if (!supported) return fail(OCD_ERR_UNSUPPORTED, "reward kernel: %d scripted cars, %d lanes", scn->desc.n_cars - 1, L);
     if (e != hipSuccess) return hip_fail(e, "reward_kernel launch");
     return OCD_OK;
 }

@@ -58,6 +58,29 @@ __device__ __forceinline__ float exp_(float x)
     return res;
 }
 
+// exp_ restricted to finite x <= 1 (every exponent on the planner path is -1/u (+1) with u > 0):
+// same operations, without the overflow and NaN selects that cannot trigger there.
+__device__ __forceinline__ float exp_le1(float x)
+{
+    const float xs = (x >= -87.0f) ? x : -87.0f;
+    const float n = rint_small(xs * 1.44269502162933349609375f);
+    float r = fma_(n, -0.693359375f, xs);
+    r = fma_(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = fma_(p, r, 1.3981999507e-3f);
+    p = fma_(p, r, 8.3334519073e-3f);
+    p = fma_(p, r, 4.1665795894e-2f);
+    p = fma_(p, r, 1.6666665459e-1f);
+    p = fma_(p, r, 5.0000001201e-1f);
+    const float r2 = r * r;
+    float e = fma_(p, r2, r);
+    e = e + 1.0f;
+    const int32_t ni = (int32_t)n;
+    const float scale = __int_as_float((ni + 127) << 23);
+    const float res = e * scale;
+    return (x >= -87.0f) ? res : 0.0f;
+}
+
 __device__ __forceinline__ void sincos_(float x, float &s_out, float &c_out)
 {
     const float n = rint_small(x * 0.636619746685028076171875f);

@@ -38,17 +38,22 @@ struct KernelParams {
     int32_t segs_used;         // trajectories per wavefront (<= 64/H); 0 = let the launcher choose
 };
 
-// (horizon, scripted cars) pairs with a compiled kernel.  Horizons 5/6: the
-// reference's own settings; 10/15/25: BASELINE.json configs 2-5; the rest for
-// tests and sweeps.  Anything else returns OCD_ERR_UNSUPPORTED.
-#define OCD_KERNEL_TABLE(X)                                                        \
-    X(3, 0) X(5, 0)                                                                \
-    X(3, 1) X(4, 1) X(5, 1) X(6, 1) X(8, 1) X(10, 1) X(12, 1) X(15, 1) X(16, 1)    \
-    X(20, 1) X(25, 1) X(32, 1)                                                     \
-    X(3, 2) X(5, 2) X(6, 2) X(8, 2) X(10, 2) X(15, 2) X(20, 2) X(25, 2) X(5, 3)
+// (horizon H, scripted cars NO, lanes L) triples with a compiled planner kernel; L = 0 is the
+// target-speed test reward (no lane features).  Horizons 5/6: the reference's own settings;
+// 10/15/25: BASELINE.json configs 2-5; the rest for tests and sweeps.  Anything else returns
+// OCD_ERR_UNSUPPORTED.
+#define OCD_KERNEL_TABLE(X)                                                                   \
+    X(3, 0, 0) X(5, 0, 0)                                                                     \
+    X(3, 1, 3) X(4, 1, 3) X(5, 1, 3) X(6, 1, 3) X(8, 1, 3) X(10, 1, 3) X(12, 1, 3)            \
+    X(15, 1, 3) X(16, 1, 3) X(20, 1, 3) X(25, 1, 3) X(32, 1, 3)                               \
+    X(5, 2, 2) X(6, 2, 2) X(10, 2, 2) X(15, 2, 2) X(20, 2, 2)                                 \
+    X(3, 2, 3) X(5, 2, 3) X(8, 2, 3) X(10, 2, 3) X(25, 2, 3) X(5, 3, 3)
 
-hipError_t launch_mpc_dispatch(int H, int NO, const KernelParams &p, hipStream_t st, bool *supported);
-hipError_t launch_reward(int NO, const KernelParams &p, float *feats, float *rew, hipStream_t st, bool *supported);
+// (scripted cars, lanes) pairs of the reward-only kernel
+#define OCD_REWARD_TABLE(X) X(0, 0) X(1, 2) X(1, 3) X(2, 2) X(2, 3) X(3, 2) X(3, 3) X(1, 1) X(2, 1) X(1, 4) X(2, 4)
+
+hipError_t launch_mpc_dispatch(int H, int NO, int L, const KernelParams &p, hipStream_t st, bool *supported);
+hipError_t launch_reward(int NO, int L, const KernelParams &p, float *feats, float *rew, hipStream_t st, bool *supported);
 hipError_t launch_math(const float *in, float *e, float *s, float *c, long long n, hipStream_t st);
 hipError_t launch_dynamics(const float *states, const float *controls, float dt, float dt_sq, float friction,
                            float *out, long long n, hipStream_t st);

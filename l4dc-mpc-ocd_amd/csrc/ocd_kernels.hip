@@ -54,7 +54,7 @@ __device__ __forceinline__ float f_fwd(float t, float shape, FTape &tp)
     const float tc = pos ? t : (0.0f + 0.01f);
     const float u = shape * tc;
     const float m = -1.0f / u;
-    const float e = exp_(m);
+    const float e = exp_le1(m);
     tp.pos = pos; tp.m = m; tp.e = e; tp.u = u;
     return pos ? e : 0.0f;
 }
@@ -106,7 +106,7 @@ __device__ __forceinline__ float bump_fwd(float z, float center, float width, Bu
     const float q = 1.0f - xc * xc;
     const float m = -1.0f / q;
     const float arg = m + 1.0f;
-    const float e = exp_(arg);
+    const float e = exp_le1(arg);
     tp.cond = cond; tp.xc = xc; tp.q = q; tp.m = m; tp.e = e;
     return cond ? e : 0.0f;
 }
@@ -186,7 +186,7 @@ __device__ __forceinline__ bool needs_collision(float x, float y, const BumpGeom
 
 // reward of one world state and (GRAD) its gradient w.r.t. the ego state
 // (merging.py:44-83, linear_reward_car.py:49-55, targetSpeedRewardMaximizerCar.py:50-56)
-template <int NO, bool GRAD>
+template <int NO, int L, bool GRAD>
 __device__ __forceinline__ float reward_state(const ocd_scenario_desc &d, const float (&w)[OCD_MAX_FEATURES],
                                               float x, float y, float v, float sn, float cn,
                                               const BumpGeom (&bg)[NO > 0 ? NO : 1], Q4 &q,
@@ -196,13 +196,12 @@ __device__ __forceinline__ float reward_state(const ocd_scenario_desc &d, const 
     // do_col / do_fence are WAVE-UNIFORM: false only when the caller has proved that, for every live
     // lane, the collision bumps / the fence thresholds are identically zero together with their
     // gradients (see needs_collision / needs_fence), so skipping them changes no bit of any result.
-    if (d.reward_kind == OCD_REWARD_TARGET_SPEED) {
+    if (L == 0) {                                  // OCD_REWARD_TARGET_SPEED (the planner KAT car)
         const float dv = v - d.target_speed;
         const float sq = dv * dv;
         if (GRAD) { q.qx = 0.0f; q.qy = 0.0f; q.qth = 0.0f; q.qv = (-1.0f * 2.0f) * dv; }
         return 0.0f - sq;
     }
-    const int L = d.n_lanes;
     float phi[OCD_MAX_FEATURES];
 
     const float tgt = d.target_speed;
@@ -213,21 +212,20 @@ __device__ __forceinline__ float reward_state(const ocd_scenario_desc &d, const 
     const bool pass0 = sq <= bound;
     phi[0] = min_tf(sq, bound);
 
-    float rl[OCD_MAX_LANES], pl[OCD_MAX_LANES];
+    constexpr int LA = L > 0 ? L : 1;
+    float rl[LA], pl[LA];
     float pmin = 0.0f;
 #pragma unroll
-    for (int l = 0; l < OCD_MAX_LANES; ++l) {
-        if (l < L) {
-            const float diff = x - d.lane_center[l];
-            rl[l] = diff * -1.0f;
-            const float d2 = rl[l] * rl[l];
-            pl[l] = d2 * 10.0f;
-            pmin = (l == 0) ? pl[0] : min_tf(pmin, pl[l]);
-        } else { rl[l] = 0.0f; pl[l] = 0.0f; }
+    for (int l = 0; l < L; ++l) {
+        const float diff = x - d.lane_center[l];
+        rl[l] = diff * -1.0f;
+        const float d2 = rl[l] * rl[l];
+        pl[l] = d2 * 10.0f;
+        pmin = (l == 0) ? pl[0] : min_tf(pmin, pl[l]);
     }
     int ntie_min = 0;
 #pragma unroll
-    for (int l = 0; l < OCD_MAX_LANES; ++l) if (l < L) ntie_min += (pl[l] == pmin) ? 1 : 0;
+    for (int l = 0; l < L; ++l) ntie_min += (pl[l] == pmin) ? 1 : 0;
 
     BumpTape bx[NO > 0 ? NO : 1], by[NO > 0 ? NO : 1];
     float bxv[NO > 0 ? NO : 1], byv[NO > 0 ? NO : 1], col[NO > 0 ? NO : 1];
@@ -263,22 +261,15 @@ __device__ __forceinline__ float reward_state(const ocd_scenario_desc &d, const 
     // reduce_sum(weights * feats), left to right over [phi0, lanes..., min, collision, fences]
     float r = w[0] * phi[0];
 #pragma unroll
-    for (int l = 0; l < OCD_MAX_LANES; ++l) if (l < L) r = r + w[1 + l] * pl[l];
-    // the feature index of min / collision / fences depends on L: select the weight registers
-    float w_min = 0.0f, w_col = 0.0f, w_f = 0.0f;
-#pragma unroll
-    for (int k = 1; k < OCD_MAX_FEATURES; ++k) {
-        w_min = (k == L + 1) ? w[k] : w_min;
-        w_col = (k == L + 2) ? w[k] : w_col;
-        w_f = (k == L + 3) ? w[k] : w_f;
-    }
+    for (int l = 0; l < L; ++l) r = r + w[1 + l] * pl[l];
+    const float w_min = w[L + 1], w_col = w[L + 2], w_f = w[L + 3];
     r = r + w_min * pmin;
     if (do_col) r = r + w_col * pcol;      // skipped terms are exactly +-0
     if (do_fence) r = r + w_f * pf;
     if (feats) {
         feats[0] = phi[0];
 #pragma unroll
-        for (int l = 0; l < OCD_MAX_LANES; ++l) if (l < L) feats[1 + l] = pl[l];
+        for (int l = 0; l < L; ++l) feats[1 + l] = pl[l];
         feats[L + 1] = pmin; feats[L + 2] = pcol; feats[L + 3] = pf;
     }
     if (!GRAD) return r;
@@ -292,14 +283,12 @@ __device__ __forceinline__ float reward_state(const ocd_scenario_desc &d, const 
     float qx = 0.0f, qy = 0.0f;
     const float min_share = w_min / (float)ntie_min;
 #pragma unroll
-    for (int l = 0; l < OCD_MAX_LANES; ++l) {
-        if (l < L) {
-            float g = w[1 + l];
-            g = (pl[l] == pmin) ? (g + min_share) : g;
-            const float g_d2 = g * 10.0f;
-            const float g_r = (g_d2 * 2.0f) * rl[l];
-            qx = qx + g_r * -1.0f;
-        }
+    for (int l = 0; l < L; ++l) {
+        float g = w[1 + l];
+        g = (pl[l] == pmin) ? (g + min_share) : g;
+        const float g_d2 = g * 10.0f;
+        const float g_r = (g_d2 * 2.0f) * rl[l];
+        qx = qx + g_r * -1.0f;
     }
     if (NO > 0 && do_col) {
         const float col_share = w_col / (float)ntie_col;
@@ -325,36 +314,48 @@ __device__ __forceinline__ float reward_state(const ocd_scenario_desc &d, const 
 }
 
 // ---------------------------------------------------------------- segment exchange through LDS
-// Each wavefront owns NARR arrays of SEGP floats; a lane writes its own slot,
-// then every lane of a segment reads the segment's H values back (broadcast
-// ds_read_b128).  Wave-synchronous: DS operations of one wavefront execute in
-// program order, so no s_barrier is needed; wave_barrier() only pins the
-// compiler's schedule.
+// The four recurrences of an SGD iteration are prefix / suffix scans over the H lanes of a segment.
+// Each lane publishes its term in LDS and then runs the scan itself, reading a lane-shifted window
+// of a ZERO-PADDED row, so that no step needs a predicate:
+//
+//      row = [ H-1 zeros | term_0 .. term_{H-1} | H-1 zeros ]          (ROW = 3H-2 elements)
+//
+//   forward  (lane t needs term_0..term_{t-1}, in that order): step i reads element i+t, i.e. H-1-t
+//            zeros first, then term_0..term_{t-1};  x + 0 == x exactly, so the leading steps are no-ops.
+//   backward (lane t needs term_{H-1}..term_{t+1}, in that order): step i reads element 2H-2+t-i, i.e.
+//            t zeros (from the upper pad) first, then term_{H-1}..term_{t+1}; the adjoint recurrences
+//            started from 0 map zero inputs to 0, so the leading steps are no-ops as well.
+//   The one recurrence with no neutral element (v' = v + (a - f v^2) dt) multiplies its increment by a
+//   per-lane 0/1 mask inside the fma: fma(delta, 1, v) == v + delta and fma(delta, 0, v) == v, bit for bit.
+//
+// Wave-synchronous: DS operations of one wavefront execute in program order, so no s_barrier is
+// needed inside the SGD loop; wave_barrier() only pins the compiler's schedule.
 template <int H>
 struct Geo {
-    static constexpr int HP = (H + 3) & ~3;          // segment stride in LDS (16-byte aligned rows)
-    static constexpr int SEGS = 64 / H;              // trajectories per wavefront
-    static constexpr int SEGP = (SEGS + 1) * HP;     // +1: lanes past the last segment park here
-    static constexpr int NARR = 6;
+    static constexpr int SEGS = 64 / H;              // trajectories per wavefront (max)
+    static constexpr int ROW = 3 * H - 2;            // padded elements per segment row
+    static constexpr int ROWS = SEGS + 1;            // +1: lanes past the last segment park here
+    // floats per wavefront: one float4 plane followed by one float2 plane
+    static constexpr int PLANE4 = ROWS * ROW * 4;
+    static constexpr int PLANE2 = ROWS * ROW * 2;
+    static constexpr int WAVE_FLOATS = (PLANE4 + PLANE2 + 3) & ~3;   // keeps every wavefront's float4 plane 16-byte aligned
+    static constexpr int SEL_FLOATS = ROWS * 4;      // selection record per (buffer, wavefront)
 };
 
-template <int H>
-__device__ __forceinline__ void seg_load(const float *row, float (&out)[Geo<H>::HP])
+// neighbour value from the lane below (lane-1) without touching LDS: DPP wave_shr:1
+__device__ __forceinline__ float lane_below(float v)
 {
-#pragma unroll
-    for (int i = 0; i < Geo<H>::HP / 4; ++i) {
-        const float4 v = *reinterpret_cast<const float4 *>(row + 4 * i);
-        out[4 * i] = v.x; out[4 * i + 1] = v.y; out[4 * i + 2] = v.z; out[4 * i + 3] = v.w;
-    }
+    const int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    return __int_as_float(r);
 }
 
 // ---------------------------------------------------------------- the kernel
-template <int H, int NO>
+template <int H, int NO, int L>
 __global__ void __launch_bounds__(64 * OCD_MAX_CTRL_INITS)
 mpc_kernel(const KernelParams p)
 {
     using G = Geo<H>;
-    constexpr int HP = G::HP, SEGS = G::SEGS, SEGP = G::SEGP, NARR = G::NARR;
+    constexpr int ROW = G::ROW;
     constexpr int NOA = NO > 0 ? NO : 1;
     const ocd_scenario_desc &d = p.d;
 
@@ -365,10 +366,25 @@ mpc_kernel(const KernelParams p)
     const int lane = threadIdx.x & 63;
     const int seg = lane / H;                 // SEGS for the parked tail lanes
     const int t = lane - seg * H;
-    float *xch = lds + (size_t)wave * NARR * SEGP;          // this wavefront's exchange arrays
-    float *sel = lds + (size_t)K * NARR * SEGP;             // [2][K][SEGS][4] selection records
-    const int slot = seg * HP + t;
-    const int rowb = seg * HP;
+    // zero the pads once (data slots are always written before they are read)
+    for (int i = threadIdx.x; i < K * G::WAVE_FLOATS; i += blockDim.x) lds[i] = 0.0f;
+    __syncthreads();
+    float4 *plane4 = reinterpret_cast<float4 *>(lds + (size_t)wave * G::WAVE_FLOATS) + seg * ROW;
+    float2 *plane2 = reinterpret_cast<float2 *>(lds + (size_t)wave * G::WAVE_FLOATS + G::PLANE4) + seg * ROW;
+    float4 *const own4 = plane4 + (H - 1 + t);               // this lane's data slot
+    float2 *const own2 = plane2 + (H - 1 + t);
+    const float2 *const fwd2 = plane2 + t;                   // forward window: element i+t at step i
+    const float4 *const bwd4 = plane4 + (2 * H - 2 + t);     // backward window: element 2H-2+t-i at step i
+    const float2 *const bwd2 = plane2 + (2 * H - 2 + t);
+    const float2 *const data2 = plane2 + (H - 1);            // the segment's H terms, in order
+    float *sel = lds + (size_t)K * G::WAVE_FLOATS;           // [2][K][ROWS][4] selection records
+    // 0/1 masks of the forward speed recurrence: step i updates lane t iff i >= H-1-t
+    float mfw[H > 1 ? H - 1 : 1];
+#pragma unroll
+    for (int i = 0; i < H - 1; ++i) {
+        mfw[i] = (i >= H - 1 - t) ? 1.0f : 0.0f;
+        asm volatile("" : "+v"(mfw[i]));                     // keep them in registers, do not rematerialise
+    }
 
     // segs_used <= SEGS trajectories per wavefront: small batches are spread over more wavefronts
     // (one trajectory each) so that the uniform feature skips act per trajectory; big batches pack.
@@ -377,7 +393,7 @@ mpc_kernel(const KernelParams p)
     const long long prob = live ? prob_raw : (p.n_problems - 1);     // parked lanes shadow a real problem
 
     const float dt = d.dt, dt2 = d.dt_sq, fr = d.ego_friction, lr = d.learning_rate;
-    const int D = d.n_lanes + 4;
+    constexpr int D = L > 0 ? L + 4 : 0;
 
     // ---- problem inputs -------------------------------------------------
     float ex, ey, ev, eth;                    // ego state
@@ -449,7 +465,7 @@ mpc_kernel(const KernelParams p)
             float s_, c_;
             sincos_(eth, s_, c_);
             Q4 qd;
-            const float r = reward_state<NO, false>(d, wd, ex, ey, ev, s_, c_, bgd, qd, nullptr);
+            const float r = reward_state<NO, L, false>(d, wd, ex, ey, ev, s_, c_, bgd, qd, nullptr);
             G_ret = G_ret + r;
         }
 
@@ -507,21 +523,15 @@ mpc_kernel(const KernelParams p)
             const bool pass_w = (uw <= 4.0f) && (w1 >= -4.0f);
             const float wdt = w_c * dt;
 
-            xch[0 * SEGP + slot] = a_c;
-            xch[1 * SEGP + slot] = wdt;
+            *own2 = make_float2(a_c, wdt);
             __builtin_amdgcn_wave_barrier();
             float v = ev, th = eth;
-            {
-                float A[HP], W[HP];
-                seg_load<H>(xch + 0 * SEGP + rowb, A);
-                seg_load<H>(xch + 1 * SEGP + rowb, W);
 #pragma unroll
-                for (int j = 0; j < H - 1; ++j) {
-                    const float vn_ = v + (A[j] - fr * (v * v)) * dt;
-                    const float thn_ = th + W[j];
-                    v = (j < t) ? vn_ : v;
-                    th = (j < t) ? thn_ : th;
-                }
+            for (int i = 0; i < H - 1; ++i) {
+                const float2 aw = fwd2[i];
+                const float delta = (aw.x - fr * (v * v)) * dt;
+                v = fma_(delta, mfw[i], v);
+                th = th + aw.y;
             }
             // own step t: (v, th) is the state before it
             const float v2 = v * v;
@@ -535,69 +545,53 @@ mpc_kernel(const KernelParams p)
             const float thn = th + wdt;
             float sn, cn;
             sincos_(thn, sn, cn);
-            float s_pre = __shfl_up(sn, 1);
-            float c_pre = __shfl_up(cn, 1);
+            float s_pre = lane_below(sn);
+            float c_pre = lane_below(cn);
             s_pre = (t == 0) ? s0 : s_pre;
             c_pre = (t == 0) ? c0 : c_pre;
             const float cd = c_pre * dd;
             const float sd = s_pre * dd;
             __builtin_amdgcn_wave_barrier();
-            xch[2 * SEGP + slot] = cd;
-            xch[3 * SEGP + slot] = sd;
+            *own2 = make_float2(cd, sd);
             __builtin_amdgcn_wave_barrier();
             float x = ex, y = ey;
-            {
-                float CD[HP], SD[HP];
-                seg_load<H>(xch + 2 * SEGP + rowb, CD);
-                seg_load<H>(xch + 3 * SEGP + rowb, SD);
 #pragma unroll
-                for (int j = 0; j < H - 1; ++j) {
-                    const float xn_ = x + CD[j];
-                    const float yn_ = y + SD[j];
-                    x = (j < t) ? xn_ : x;
-                    y = (j < t) ? yn_ : y;
-                }
+            for (int i = 0; i < H - 1; ++i) {
+                const float2 c2 = fwd2[i];
+                x = x + c2.x;
+                y = y + c2.y;
             }
             const float xn = x + cd;
             const float yn = y + sd;
 
             Q4 q;
-            const bool lane_feats = d.reward_kind == OCD_REWARD_LANE_FEATURES;
+            constexpr bool lane_feats = L > 0;
             const bool do_fence = lane_feats && (__ballot(live && needs_fence(d, xn)) != 0ull);
             const bool do_col = lane_feats && (NO > 0) && (__ballot(live && needs_collision<NO>(xn, yn, bg)) != 0ull);
             if (it == n_iter) {
                 // ===== last pass: objective only (naive_planner.py:154) =====
-                const float r = reward_state<NO, false>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, do_col, do_fence);
+                const float r = reward_state<NO, L, false>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, do_col, do_fence);
                 __builtin_amdgcn_wave_barrier();
-                xch[4 * SEGP + slot] = r;
+                *own2 = make_float2(r, 0.0f);
                 __builtin_amdgcn_wave_barrier();
-                float R[HP];
-                seg_load<H>(xch + 4 * SEGP + rowb, R);
                 float Rsum = 0.0f;
 #pragma unroll
-                for (int j = 0; j < H; ++j) Rsum = Rsum + R[j];
+                for (int j = 0; j < H; ++j) Rsum = Rsum + data2[j].x;
                 loss = -Rsum;
                 break;
             }
-            reward_state<NO, true>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, do_col, do_fence);
+            reward_state<NO, L, true>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, do_col, do_fence);
 
             // ===== backward =====
             __builtin_amdgcn_wave_barrier();
-            xch[0 * SEGP + slot] = q.qx;
-            xch[1 * SEGP + slot] = q.qy;
+            *own2 = make_float2(q.qx, q.qy);
             __builtin_amdgcn_wave_barrier();
             float Lx = 0.0f, Ly = 0.0f;
-            {
-                float QX[HP], QY[HP];
-                seg_load<H>(xch + 0 * SEGP + rowb, QX);
-                seg_load<H>(xch + 1 * SEGP + rowb, QY);
 #pragma unroll
-                for (int j = H - 1; j >= 1; --j) {
-                    const float ax_ = QX[j] + Lx;
-                    const float ay_ = QY[j] + Ly;
-                    Lx = (j > t) ? ax_ : Lx;
-                    Ly = (j > t) ? ay_ : Ly;
-                }
+            for (int i = 0; i < H - 1; ++i) {
+                const float2 qq = bwd2[-i];
+                Lx = qq.x + Lx;
+                Ly = qq.y + Ly;
             }
             const float Ax = q.qx + Lx;
             const float Ay = q.qy + Ly;
@@ -608,34 +602,21 @@ mpc_kernel(const KernelParams p)
             const float gv1 = g_d * dt;
             const float gA1 = (g_d * dt2) * 0.5f;
             __builtin_amdgcn_wave_barrier();
-            xch[0 * SEGP + slot] = q.qv;
-            xch[1 * SEGP + slot] = gA1;
-            xch[2 * SEGP + slot] = gv1;
-            xch[3 * SEGP + slot] = v;
-            xch[4 * SEGP + slot] = q.qth;
-            xch[5 * SEGP + slot] = tau;
+            *own4 = make_float4(q.qv, gA1, gv1, v);
+            *own2 = make_float2(q.qth, tau);
             __builtin_amdgcn_wave_barrier();
             float Lv = 0.0f, Lth = 0.0f;
-            {
-                float QV[HP], GA1[HP], GV1[HP], VV[HP], QTH[HP], TAU[HP];
-                seg_load<H>(xch + 0 * SEGP + rowb, QV);
-                seg_load<H>(xch + 1 * SEGP + rowb, GA1);
-                seg_load<H>(xch + 2 * SEGP + rowb, GV1);
-                seg_load<H>(xch + 3 * SEGP + rowb, VV);
-                seg_load<H>(xch + 4 * SEGP + rowb, QTH);
-                seg_load<H>(xch + 5 * SEGP + rowb, TAU);
 #pragma unroll
-                for (int j = H - 1; j >= 1; --j) {
-                    const float Av_ = QV[j] + Lv;
-                    const float gA_ = GA1[j] + Av_ * dt;
-                    const float gv2_ = (-gA_) * fr;
-                    const float gv3_ = (gv2_ * 2.0f) * VV[j];
-                    const float Lv_ = (GV1[j] + Av_) + gv3_;
-                    const float Ath_ = QTH[j] + Lth;
-                    const float Lth_ = Ath_ + TAU[j];
-                    Lv = (j > t) ? Lv_ : Lv;
-                    Lth = (j > t) ? Lth_ : Lth;
-                }
+            for (int i = 0; i < H - 1; ++i) {
+                const float4 b = bwd4[-i];                 // (qv, gA1, gv1, v) of step j = H-1-i+t, or zeros
+                const float2 a = bwd2[-i];                 // (qth, tau)
+                const float Av_ = b.x + Lv;
+                const float gA_ = b.y + Av_ * dt;
+                const float gv2_ = (-gA_) * fr;
+                const float gv3_ = (gv2_ * 2.0f) * b.w;
+                Lv = (b.z + Av_) + gv3_;
+                const float Ath_ = a.x + Lth;
+                Lth = Ath_ + a.y;
             }
             const float Av = q.qv + Lv;
             const float gA = gA1 + Av * dt;
@@ -658,19 +639,19 @@ mpc_kernel(const KernelParams p)
         }
 
         // ---- first-index argmin over the K initialisations (naive_planner.py:161-162) ----
-        float *selb = sel + (size_t)(step & 1) * K * (SEGS + 1) * 4;
+        float *selb = sel + (size_t)(step & 1) * K * G::SEL_FLOATS;
         if (t == 0) {
-            float *rec = selb + ((size_t)wave * (SEGS + 1) + seg) * 4;
+            float *rec = selb + ((size_t)wave * G::ROWS + seg) * 4;
             rec[0] = loss; rec[1] = ua; rec[2] = uw;
         }
         __syncthreads();
         int best = 0;
-        float bl = selb[((size_t)0 * (SEGS + 1) + seg) * 4];
+        float bl = selb[((size_t)0 * G::ROWS + seg) * 4];
         for (int k = 1; k < K; ++k) {
-            const float lk = selb[((size_t)k * (SEGS + 1) + seg) * 4];
+            const float lk = selb[((size_t)k * G::ROWS + seg) * 4];
             if (lk < bl) { bl = lk; best = k; }
         }
-        const float *brec = selb + ((size_t)best * (SEGS + 1) + seg) * 4;
+        const float *brec = selb + ((size_t)best * G::ROWS + seg) * 4;
         const float ca = brec[1], cw = brec[2];
 
         if (p.mode == OCD_MODE_PLAN) {
@@ -719,14 +700,14 @@ mpc_kernel(const KernelParams p)
 }
 
 // ---------------------------------------------------------------- small kernels
-template <int NO>
+template <int NO, int L>
 __global__ void reward_kernel(const KernelParams p, float *feats_out, float *reward_out)
 {
     constexpr int NOA = NO > 0 ? NO : 1;
     const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= p.n_problems) return;
     const ocd_scenario_desc &d = p.d;
-    const int D = d.n_lanes + 4;
+    constexpr int D = L > 0 ? L + 4 : 0;
     const float *ws = p.ego_states + b * (NO + 1) * 4;
     float w[OCD_MAX_FEATURES];
 #pragma unroll
@@ -738,7 +719,7 @@ __global__ void reward_kernel(const KernelParams p, float *feats_out, float *rew
     float s_, c_;
     sincos_(ws[3], s_, c_);
     Q4 q;
-    const float r = reward_state<NO, false>(d, w, ws[0], ws[1], ws[2], s_, c_, bg, q,
+    const float r = reward_state<NO, L, false>(d, w, ws[0], ws[1], ws[2], s_, c_, bg, q,
                                             feats_out ? feats_out + b * D : nullptr);
     if (reward_out) reward_out[b] = r;
 }
@@ -774,18 +755,18 @@ __global__ void math_kernel(const float *in, float *e, float *s, float *c, long 
 // ---------------------------------------------------------------- launch table
 namespace ocd {
 
-template <int H, int NO>
+template <int H, int NO, int L>
 static hipError_t launch_mpc(const KernelParams &p, hipStream_t st)
 {
     using G = Geo<H>;
     const int K = p.K;
     const long long blocks = (p.n_problems + p.segs_used - 1) / p.segs_used;
-    const size_t lds = ((size_t)K * G::NARR * G::SEGP + (size_t)2 * K * (G::SEGS + 1) * 4) * sizeof(float);
-    hipLaunchKernelGGL((mpc_kernel<H, NO>), dim3((unsigned)blocks), dim3(64 * K), lds, st, p);
+    const size_t lds = ((size_t)K * G::WAVE_FLOATS + (size_t)2 * K * G::SEL_FLOATS) * sizeof(float);
+    hipLaunchKernelGGL((mpc_kernel<H, NO, L>), dim3((unsigned)blocks), dim3(64 * K), lds, st, p);
     return hipGetLastError();
 }
 
-#define OCD_CASE(HH, NN) if (H == HH && NO == NN) return launch_mpc<HH, NN>(p, st);
+#define OCD_CASE(HH, NN, LL) if (H == HH && NO == NN && L == LL) return launch_mpc<HH, NN, LL>(p, st);
 
 // Trajectories per wavefront for a launch of n problems: one per wavefront while that still leaves
 // SIMDs idle (256 CUs x 4 SIMDs), which keeps the uniform feature skips per trajectory; beyond that,
@@ -801,7 +782,7 @@ int choose_segs(int H, long long n_problems, int K)
     return (int)segs;
 }
 
-hipError_t launch_mpc_dispatch(int H, int NO, const KernelParams &p_in, hipStream_t st, bool *supported)
+hipError_t launch_mpc_dispatch(int H, int NO, int L, const KernelParams &p_in, hipStream_t st, bool *supported)
 {
     KernelParams p = p_in;
     if (p.segs_used <= 0) p.segs_used = choose_segs(H, p.n_problems, p.K);
@@ -812,19 +793,16 @@ hipError_t launch_mpc_dispatch(int H, int NO, const KernelParams &p_in, hipStrea
     return hipSuccess;
 }
 
-hipError_t launch_reward(int NO, const KernelParams &p, float *feats, float *rew, hipStream_t st, bool *supported)
+#define OCD_RCASE(NN, LL) if (NO == NN && L == LL) { hipLaunchKernelGGL((reward_kernel<NN, LL>), dim3(nb), dim3(bs), 0, st, p, feats, rew); return hipGetLastError(); }
+
+hipError_t launch_reward(int NO, int L, const KernelParams &p, float *feats, float *rew, hipStream_t st, bool *supported)
 {
     *supported = true;
     const unsigned bs = 256;
     const unsigned nb = (unsigned)((p.n_problems + bs - 1) / bs);
-    switch (NO) {
-    case 0: hipLaunchKernelGGL((reward_kernel<0>), dim3(nb), dim3(bs), 0, st, p, feats, rew); break;
-    case 1: hipLaunchKernelGGL((reward_kernel<1>), dim3(nb), dim3(bs), 0, st, p, feats, rew); break;
-    case 2: hipLaunchKernelGGL((reward_kernel<2>), dim3(nb), dim3(bs), 0, st, p, feats, rew); break;
-    case 3: hipLaunchKernelGGL((reward_kernel<3>), dim3(nb), dim3(bs), 0, st, p, feats, rew); break;
-    default: *supported = false; return hipSuccess;
-    }
-    return hipGetLastError();
+    OCD_REWARD_TABLE(OCD_RCASE)
+    *supported = false;
+    return hipSuccess;
 }
 
 hipError_t launch_dynamics(const float *states, const float *controls, float dt, float dt_sq, float friction,
