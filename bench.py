@@ -26,6 +26,22 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak fp32 vector
 
 
+def pmc_traffic_bytes(cfg, n_episodes):
+    """HBM bytes per launch of the episode kernel from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json: FETCH_SIZE + WRITE_SIZE, separate --pmc runs of this same command,
+    KiB -> bytes; dword-granular accesses, so the guide's 2x FETCH correction for wide streaming
+    reads does not apply).  None when no profile of this workload is committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f).get(f"cfg{cfg}")
+    except (OSError, ValueError):
+        return None
+    if not rec or rec.get("episodes_per_launch") != n_episodes:
+        return None
+    return (rec["fetch_kib"] + rec["write_kib"]) * 1024.0
+
+
 def algorithmic_per_episode(desc):
     """compulsory HBM bytes and flops of one episode."""
     T, H, I = desc.episode_len, desc.horizon, desc.n_iter
@@ -89,6 +105,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json config index (2..5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (default); gloo only to rehearse N>1 on a one-GPU box")
     args = ap.parse_args()
 
     import torch
@@ -99,11 +117,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs an MI355X: the planner has no CPU fallback")
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    device = f"cuda:{dev_index}"
     if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    device = f"cuda:{local_rank}"
-    torch.cuda.set_device(local_rank)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(device))
+        else:
+            dist.init_process_group("gloo")
 
     cfg = scenarios.BASELINE_CONFIGS[args.config]
     scn = scenarios.SCENARIOS[cfg["scenario"]](horizon=cfg["horizon"])
@@ -123,7 +147,8 @@ def main():
     def generation():
         eng._call(eng.lib.ocd_rollout_episodes, eng._h, init_dev.data_ptr(), w_dev.data_ptr(), P, N, e0, e1,
                   ret_dev.data_ptr(), None, None, eng._stream())
-        full = sharding.gather_returns(ret_dev, P, N, S)
+        local = ret_dev if (world == 1 or args.backend == "nccl") else ret_dev.cpu()
+        full = sharding.gather_returns(local, P, N, S)
         return sharding.fitness_from_returns(full.cpu().numpy(), P, N, S)
 
     for _ in range(args.warmup):
@@ -139,7 +164,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        tt = torch.tensor([dt], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -171,7 +196,7 @@ def main():
                        "episodes_per_generation": E, "episodes_per_gpu": n_local,
                        "sharding": f"candidate blocks over {world} rank(s); one all_gather of fp32 returns per generation"},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(args.config, n_local),
                          "kernel": "ocd::mpc_kernel", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_episode": nbytes,
                          "note": "path is fp32-VALU/latency bound, not HBM bound (SURVEY.md 8d); see valu"},

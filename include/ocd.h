@@ -117,7 +117,9 @@ int32_t ocd_device_count(void);
 const char *ocd_last_error(void);
 
 /* Process-wide tuning knobs; results never depend on them.
- *   "segs_per_wave": trajectories packed into one wavefront (1..64/H), 0 = automatic. */
+ *   "segs_per_wave": trajectories packed into one wavefront (1..64/H), 0 = automatic;
+ *   "no_feature_skips": 1 = evaluate the collision and fence features even where they are
+ *                       provably zero (diagnostics; default 0). */
 int32_t ocd_set_option(const char *name, int32_t value);
 
 /* Validate a descriptor and build the handle the kernels read their constants

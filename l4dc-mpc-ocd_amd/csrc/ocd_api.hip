@@ -34,6 +34,7 @@ namespace {
 
 thread_local char g_err[512] = "";
 std::atomic<int32_t> g_opt_segs{0};        // "segs_per_wave": 0 = automatic
+std::atomic<int32_t> g_opt_no_skips{0};    // "no_feature_skips": 1 = always evaluate every feature
 
 int32_t fail(int32_t status, const char *fmt, ...)
 {
@@ -95,6 +96,7 @@ void base_params(const ocd_scenario *scn, ocd::KernelParams &p)
     p.K = scn->K;
     p.S = scn->desc.n_samples;
     p.segs_used = g_opt_segs.load();
+    p.no_skips = g_opt_no_skips.load();
 }
 
 int32_t launch(const ocd_scenario *scn, const ocd::KernelParams &p, void *hip_stream)
@@ -131,6 +133,10 @@ int32_t ocd_set_option(const char *name, int32_t value)
     if (std::strcmp(name, "segs_per_wave") == 0) {
         if (value < 0 || value > 64) return fail(OCD_ERR_INVALID_ARG, "segs_per_wave %d out of [0,64]", value);
         g_opt_segs.store(value);
+        return OCD_OK;
+    }
+    if (std::strcmp(name, "no_feature_skips") == 0) {
+        g_opt_no_skips.store(value ? 1 : 0);
         return OCD_OK;
     }
     return fail(OCD_ERR_INVALID_ARG, "unknown option '%s'", name);

@@ -165,12 +165,14 @@ def test_results_do_not_depend_on_packing(oracle, eng_factory, hip, segs):
     w = np.stack([scenarios.planner_weights_fp32(c) for c in scn.candidate_weights(29, seed=78)])
     ref = oracle.plan_batch(scn.desc, ws, w)
     assert hip.ocd_set_option(b"segs_per_wave", segs) == 0
+    assert hip.ocd_set_option(b"no_feature_skips", segs % 2) == 0       # skips on and off
     try:
         out = eng.plan_batch(ws, w, want_all=True)
         inits = scn.init_dist.sample(5, seed=79)
         ro = eng.rollout(inits, w[:2], want_traj=True)
     finally:
         hip.ocd_set_option(b"segs_per_wave", 0)
+        hip.ocd_set_option(b"no_feature_skips", 0)
     assert_bitwise(out["all_plans"], ref["all_plans"]); assert_bitwise(out["all_losses"], ref["all_losses"])
     rr = oracle.rollout(scn.desc, inits, w[:2], want_traj=True)
     assert_bitwise(ro["traj"], rr["traj"]); assert_bitwise(ro["returns"], rr["returns"])

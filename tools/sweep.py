@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--segs", default="0")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--pop-scale", type=int, default=1, help="multiply the population (bigger batches)")
+    ap.add_argument("--no-skips", type=int, default=0)
     a = ap.parse_args()
     import torch
     from l4dc_mpc_ocd_amd import scenarios
@@ -31,6 +32,7 @@ def main():
         w_dev = torch.as_tensor(w32).cuda()
         E = P * N * S
         ret = torch.empty(E, dtype=torch.float32, device="cuda")
+        eng.lib.ocd_set_option(b"no_feature_skips", a.no_skips)
         for segs in [int(s) for s in a.segs.split(",")]:
             assert eng.lib.ocd_set_option(b"segs_per_wave", segs) == 0
             eng.time_rollout(init_dev, w_dev, 0, E, ret, 1)
