@@ -74,7 +74,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(scn, inits, w32, budget_s=15.0):
+def cpu_baseline(scn, inits, w32, budget_s=20.0):
     """The CPU oracle (kind "port") timed on this host's cores on a bounded sample of the workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
