@@ -121,6 +121,13 @@ def load_hip_library(path: Optional[str] = None) -> C.CDLL:
     if _lib is not None and path is None:
         return _lib
     p = path or HIP_LIB_PATH
+    if not os.path.exists(p) and path is None:
+        # a source-only checkout: compile the library (hipcc cross-compiles gfx950 without a GPU).
+        # This builds the product; it is not a fallback -- if it fails, loading fails.
+        import subprocess
+        r = subprocess.run(["make", "-C", os.path.dirname(p), "all"], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise FileNotFoundError(f"{p} is missing and `make -C {os.path.dirname(p)}` failed:\n{r.stderr[-2000:]}")
     if not os.path.exists(p):
         raise FileNotFoundError(
             f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -1,0 +1,101 @@
+"""Command-line driver.  Mirrors experiments/run_mpc_ord.py:19-127 (scenario table, seeds -> init
+states, random / cmaes dispatch, history pickle name).  `vis` is out of scope (pyglet / moviepy).
+
+    python -m l4dc_mpc_ocd_amd.interact_drive.experiments.run_mpc_ord finite_horizon cmaes --n_inits 3 --seed 1
+"""
+from argparse import ArgumentParser
+
+import numpy as np
+
+from .local_opt_scenario import local_opt_env
+from .replanning_world import setup_world as replanning_env
+from ..reward_design.mpc_ord import MPC_ORD, finite_horizon_env
+
+
+def fmt(arr):
+    s = str(arr).replace("\n", ' ').replace('\t', " ")
+    while '  ' in s:
+        s = s.replace('  ', ' ')
+    return s
+
+
+envs = {
+    'local_opt': {
+        'make_env': local_opt_env, 'eval_horizon': 15,
+        'init_offset_range': [[0., -0.1, 0., 0.], [0., 0.1, 0., 0.]], 'num_eval_samples': 1,
+        'tuned_weights': np.array([-0.09686739, 0.25720383, -0.58355971, -0.23075428, -0.41237239,
+                                   -0.4758984, -0.36625558])},
+    'finite_horizon': {
+        'make_env': finite_horizon_env, 'eval_horizon': 15,
+        'init_offset_range': [[-0.1, 0., 0., 0.], [0.1, 0., 0., 0.]], 'num_eval_samples': 1,
+        'tuned_weights': np.array([-0.21963165, -0.01184596, 0.34379187, -0.04687411, -0.06364365,
+                                   -0.54138792, -0.7308079])},
+    'replanning': {
+        'make_env': replanning_env, 'eval_horizon': 20,
+        'init_offset_range': [[-0.05, 0., 0., 0.], [0.05, 0., 0., 0.]], 'num_eval_samples': 2,
+        'tuned_weights': np.array([-0.55899817, -0.4436692, -0.3724511, -0.19964276, -0.5438697, 0.12770043])},
+}
+
+
+def run_opt(env, init_states, args, optimization_seed):
+    car, world, _ = env['make_env'](debug=True)
+    save_path = (f'{args.optimizer}_{args.scenario}__designer_weights_{fmt(car.weights)}__'
+                 f'{args.n_inits if not args.one_by_one else fmt(init_states[0])}_init_seed_{args.seed}'
+                 f'_opt_seed_{optimization_seed}_sigma_{args.sigma}.pkl')
+    mpc_ord = MPC_ORD(world, car, init_states, env['eval_horizon'], num_samples=env['num_eval_samples'],
+                      save_path=save_path if args.save else None)
+    if args.optimizer == 'random':
+        best = mpc_ord.optimize_random_search(n_iter=args.n_random, seed=optimization_seed % (2 ** 32))
+        return mpc_ord, best[0]
+    assert args.optimizer == 'cmaes'
+    best = mpc_ord.optimize_cmaes(sigma0=args.sigma, seed=optimization_seed, popsize=args.popsize,
+                                  maxiter=args.maxiter, maxfevals=args.maxfevals)
+    return mpc_ord, best
+
+
+def main(argv=None):
+    parser = ArgumentParser()
+    parser.add_argument('scenario', type=str, choices=['local_opt', 'finite_horizon', 'replanning'])
+    parser.add_argument('optimizer', type=str, choices=['random', 'cmaes', 'vis'])
+    parser.add_argument('--n_inits', type=int, default=1)
+    parser.add_argument('--seed', type=int, default=None)
+    parser.add_argument('--one_by_one', action='store_true',
+                        help='Runs single init optimization separately for each init.')
+    parser.add_argument('--rand_inits', action='store_true')
+    parser.add_argument('--sigma', type=float, default=0.05)
+    # additions of this build (the reference hard-codes 400 random evaluations and pycma's defaults)
+    parser.add_argument('--n_random', type=int, default=400)
+    parser.add_argument('--popsize', type=int, default=None)
+    parser.add_argument('--maxiter', type=int, default=None)
+    parser.add_argument('--maxfevals', type=int, default=85, help='CMA-ES evaluations (85 are used in the paper plots)')
+    parser.add_argument('--save', action='store_true', help='write the (weights, reward) history pickle')
+    args = parser.parse_args(argv)
+    assert args.n_inits >= 1
+    assert args.seed != 0, 'CMA doesn\'t accept 0 seed'
+    if args.optimizer == 'vis':
+        raise SystemExit("'vis' renders GIFs / heat maps with pyglet + moviepy: outside the accelerated planner path")
+    if args.n_inits == 1:
+        args.one_by_one = False
+    env = envs[args.scenario]
+    optimization_seed = np.random.randint(0, 2 ** 31)
+    if args.seed is None:
+        args.seed = optimization_seed
+    env_seeds = [(args.seed * 1000000 + i) % (2 ** 32) for i in range(args.n_inits)]
+    car, world, init_states = env['make_env'](env_seeds=env_seeds, debug=True)
+    init_states_groups = [[s] for s in init_states] if args.one_by_one else [init_states]
+    print('init_states:', init_states_groups)
+    results = []
+    for group in init_states_groups:
+        mpc_ord, best = run_opt(env, group, args, optimization_seed)
+        top = max(mpc_ord.history, key=lambda a: a[1])
+        print(f'evaluations {len(mpc_ord.history)}  designer-weights reward {mpc_ord.history[0][1]:.6f}  '
+              f'best reward {top[1]:.6f}  best weights {fmt(top[0])}')
+        if getattr(mpc_ord, "generation_seconds", None):
+            gs = mpc_ord.generation_seconds
+            print(f'CMA-ES generations {len(gs)}  median generation wall-clock {np.median(gs) * 1e3:.2f} ms')
+        results.append((mpc_ord, best))
+    return results
+
+
+if __name__ == '__main__':
+    main()

@@ -88,6 +88,17 @@ class MPC_ORD:
         self.car.init_state = type(self.car.state)(init)
         return designer_reward
 
+    def eval_weights_for_inits(self, weights_2d, inits):
+        """[W, D] weight vectors x [N, 4] init states -> [W, N] designer returns (fp32, summed over
+        samples): the held-out generalisation sweep of experiments/generalization_data.py:64-107
+        (eval_weights_for_init for every (test_init, chosen_weights) pair) as one launch."""
+        W = np.asarray(weights_2d, dtype=np.float64).reshape(-1, self.weight_dim)
+        ret = self._returns(inits, W)                                  # [W, N, S]
+        out = np.zeros(ret.shape[:2], dtype=np.float32)
+        for s in range(ret.shape[2]):
+            out = (out + ret[:, :, s]).astype(np.float32)
+        return out
+
     def eval_population(self, weights_2d):
         """[P, D] candidate weights -> [P] costs (-expected designer return), one launch per rank."""
         W = np.asarray(weights_2d, dtype=np.float64).reshape(-1, self.weight_dim)

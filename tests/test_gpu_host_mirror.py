@@ -197,3 +197,33 @@ def test_reward_fn_and_features_match_oracle(hip, oracle):
     r_ref, f_ref, _ = oracle.reward(scn.desc, np.stack(state), car.weights)
     assert same(car.reward_fn(state, None), r_ref) and same(car.features(state, None), f_ref)
     assert f_ref[5] > 0 and f_ref[6] > 0                      # collision and fence features are live here
+
+
+def test_cli_generalization_and_heatmap(hip, oracle, capsys):
+    from l4dc_mpc_ocd_amd.interact_drive.experiments import run_mpc_ord
+    from l4dc_mpc_ocd_amd.interact_drive.experiments.generalization_data import generalization_table
+    from l4dc_mpc_ocd_amd.interact_drive.reward_design.heatmap import reward_heatmap
+    res = run_mpc_ord.main(["finite_horizon", "cmaes", "--n_inits", "2", "--seed", "3", "--maxiter", "1"])
+    assert len(res) == 1 and len(res[0][0].history) == 1 + 9
+    assert "median generation wall-clock" in capsys.readouterr().out
+    res = run_mpc_ord.main(["replanning", "random", "--n_inits", "2", "--seed", "3", "--n_random", "3", "--one_by_one"])
+    assert len(res) == 2 and all(len(r[0].history) == 4 for r in res)
+    with pytest.raises(SystemExit):
+        run_mpc_ord.main(["local_opt", "vis"])
+    # generalisation sweep: every (weights, test init) pair equals the scalar reference call
+    scn = scenarios.finite_horizon(horizon=5)
+    chosen = {(1, 2): scn.tuned_weights, (3, 2): scn.raw_designer_weights}
+    inits = scn.init_dist.sample(4, seed=12)
+    table = generalization_table("finite_horizon", chosen, test_inits=inits)
+    for k, w in chosen.items():
+        ref = oracle.rollout(scn.desc, inits, scenarios.planner_weights_fp32(w)[None])["returns"]
+        assert same(table[k], ref)
+    # heat map == oracle reward on the same grid
+    car, world, _ = finite_horizon_env(horizon=5, env_seeds=[4])
+    img = reward_heatmap(car, world, size=(16, 24))
+    assert img.shape == (24, 16) and img.dtype == np.float32
+    xs = np.linspace(-0.15 + 1e-6, 0.15 - 1e-6, 16); ys = np.linspace(-1.0 + 1e-6, 1.0 - 1e-6, 24)
+    st = np.stack([np.asarray(c.state, dtype=np.float32) for c in world.cars])
+    for (j, i) in [(0, 0), (11, 7), (23, 15), (7, 15)]:
+        ws = st.copy(); ws[0, 0] = xs[i]; ws[0, 1] = ys[j]
+        assert same(img[j, i], oracle.reward(scn.desc, ws, car.weights)[0])
