@@ -342,12 +342,9 @@ struct Geo {
     static constexpr int SEL_FLOATS = ROWS * 4;      // selection record per (buffer, wavefront)
 };
 
-// value of lane `src` (a compile-time lane of segment 0) as a wave-uniform scalar: v_readlane_b32.
-// Used by the UNPACKED variant (one trajectory per wavefront), where every scan term lives in a
-// known lane, instead of an LDS round trip whose latency a lone wavefront cannot hide.
-__device__ __forceinline__ float lane_value(float v, int src)
+__device__ __forceinline__ bool finite_(float v)
 {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+    return (__float_as_uint(v) & 0x7f800000u) != 0x7f800000u;
 }
 
 // neighbour value from the lane below (lane-1) without touching LDS: DPP wave_shr:1
@@ -358,11 +355,7 @@ __device__ __forceinline__ float lane_below(float v)
 }
 
 // ---------------------------------------------------------------- the kernel
-// PACKED = true : up to 64/H trajectories per wavefront, scans through the zero-padded LDS windows.
-// PACKED = false: one trajectory per wavefront (small batches: more wavefronts than trajectories are
-//                 available anyway), scan terms broadcast with v_readlane_b32 -- no LDS latency on
-//                 the critical path of a wavefront that has its SIMD to itself.
-template <int H, int NO, int L, bool PACKED>
+template <int H, int NO, int L>
 __global__ void __launch_bounds__(64 * OCD_MAX_CTRL_INITS)
 mpc_kernel(const KernelParams p)
 {
@@ -390,15 +383,12 @@ mpc_kernel(const KernelParams p)
     const float2 *const bwd2 = plane2 + (2 * H - 2 + t);
     const float2 *const data2 = plane2 + (H - 1);            // the segment's H terms, in order
     float *sel = lds + (size_t)K * G::WAVE_FLOATS;           // [2][K][ROWS][4] selection records
-    // 0/1 masks.  PACKED: forward speed recurrence, step i updates lane t iff i >= H-1-t.
-    // UNPACKED: step j of a forward scan applies to lane t iff j < t (mfw), of a backward scan iff j > t (mbw).
-    float mfw[H > 1 ? H - 1 : 1], mbw[H > 1 ? H - 1 : 1];
+    // 0/1 masks of the forward speed recurrence: step i updates lane t iff i >= H-1-t
+    float mfw[H > 1 ? H - 1 : 1];
 #pragma unroll
     for (int i = 0; i < H - 1; ++i) {
-        mfw[i] = PACKED ? ((i >= H - 1 - t) ? 1.0f : 0.0f) : ((i < t) ? 1.0f : 0.0f);
-        mbw[i] = (i + 1 > t) ? 1.0f : 0.0f;                  // step j = i+1
+        mfw[i] = (i >= H - 1 - t) ? 1.0f : 0.0f;
         asm volatile("" : "+v"(mfw[i]));                     // keep them in registers, do not rematerialise
-        if (!PACKED) asm volatile("" : "+v"(mbw[i]));
     }
 
     // segs_used <= SEGS trajectories per wavefront: small batches are spread over more wavefronts
@@ -526,6 +516,10 @@ mpc_kernel(const KernelParams p)
         float ua = (wave >= 3) ? a_coast : 0.0f;
         float uw = (k3 == 0) ? 0.0f : ((k3 == 1) ? -0.65f : 0.65f);
 
+        // fma(delta, 0, v) == v needs a finite delta; in the masked steps delta is a function of the
+        // CURRENT speed ev only, so one wave-uniform test per control step selects the exact fallback
+        // (the world state itself can overflow after enough hard-braking steps; see the tests).
+        const bool ev_finite = __ballot(!finite_(ev)) == 0ull;
         float loss = 0.0f;
         const int n_iter = d.n_iter;
         for (int it = 0; it <= n_iter; ++it) {
@@ -539,22 +533,23 @@ mpc_kernel(const KernelParams p)
             const float wdt = w_c * dt;
 
             float v = ev, th = eth;
-            if (PACKED) {
-                *own2 = make_float2(a_c, wdt);
-                __builtin_amdgcn_wave_barrier();
+            *own2 = make_float2(a_c, wdt);
+            __builtin_amdgcn_wave_barrier();
+            if (ev_finite) {
 #pragma unroll
                 for (int i = 0; i < H - 1; ++i) {
                     const float2 aw = fwd2[i];
                     const float delta = (aw.x - fr * (v * v)) * dt;
-                    v = fma_(delta, mfw[i], v);
+                    v = fma_(delta, mfw[i], v);            // masked (leading) steps see v = ev: delta is finite
                     th = th + aw.y;
                 }
-            } else {
+            } else {                                       // a non-finite current speed: exact selects
 #pragma unroll
-                for (int j = 0; j < H - 1; ++j) {
-                    const float delta = (lane_value(a_c, j) - fr * (v * v)) * dt;
-                    v = fma_(delta, mfw[j], v);                  // v + delta for j < t, v otherwise
-                    th = fma_(lane_value(wdt, j), mfw[j], th);   // th + w*1 == th + w, th + w*0 == th
+                for (int i = 0; i < H - 1; ++i) {
+                    const float2 aw = fwd2[i];
+                    const float vn_ = v + (aw.x - fr * (v * v)) * dt;
+                    v = (i >= H - 1 - t) ? vn_ : v;
+                    th = th + aw.y;
                 }
             }
             // own step t: (v, th) is the state before it
@@ -576,22 +571,14 @@ mpc_kernel(const KernelParams p)
             const float cd = c_pre * dd;
             const float sd = s_pre * dd;
             float x = ex, y = ey;
-            if (PACKED) {
-                __builtin_amdgcn_wave_barrier();
-                *own2 = make_float2(cd, sd);
-                __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_wave_barrier();
+            *own2 = make_float2(cd, sd);
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int i = 0; i < H - 1; ++i) {
-                    const float2 c2 = fwd2[i];
-                    x = x + c2.x;
-                    y = y + c2.y;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < H - 1; ++j) {
-                    x = fma_(lane_value(cd, j), mfw[j], x);
-                    y = fma_(lane_value(sd, j), mfw[j], y);
-                }
+            for (int i = 0; i < H - 1; ++i) {
+                const float2 c2 = fwd2[i];
+                x = x + c2.x;
+                y = y + c2.y;
             }
             const float xn = x + cd;
             const float yn = y + sd;
@@ -604,16 +591,11 @@ mpc_kernel(const KernelParams p)
                 // ===== last pass: objective only (naive_planner.py:154) =====
                 const float r = reward_state<NO, L, false>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, do_col, do_fence);
                 float Rsum = 0.0f;
-                if (PACKED) {
-                    __builtin_amdgcn_wave_barrier();
-                    *own2 = make_float2(r, 0.0f);
-                    __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_wave_barrier();
+                *own2 = make_float2(r, 0.0f);
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                    for (int j = 0; j < H; ++j) Rsum = Rsum + data2[j].x;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < H; ++j) Rsum = Rsum + lane_value(r, j);
-                }
+                for (int j = 0; j < H; ++j) Rsum = Rsum + data2[j].x;
                 loss = -Rsum;
                 break;
             }
@@ -621,22 +603,14 @@ mpc_kernel(const KernelParams p)
 
             // ===== backward =====
             float Lx = 0.0f, Ly = 0.0f;
-            if (PACKED) {
-                __builtin_amdgcn_wave_barrier();
-                *own2 = make_float2(q.qx, q.qy);
-                __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_wave_barrier();
+            *own2 = make_float2(q.qx, q.qy);
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int i = 0; i < H - 1; ++i) {
-                    const float2 qq = bwd2[-i];
-                    Lx = qq.x + Lx;
-                    Ly = qq.y + Ly;
-                }
-            } else {
-#pragma unroll
-                for (int j = H - 1; j >= 1; --j) {
-                    Lx = fma_(lane_value(q.qx, j), mbw[j - 1], Lx);
-                    Ly = fma_(lane_value(q.qy, j), mbw[j - 1], Ly);
-                }
+            for (int i = 0; i < H - 1; ++i) {
+                const float2 qq = bwd2[-i];
+                Lx = qq.x + Lx;
+                Ly = qq.y + Ly;
             }
             const float Ax = q.qx + Lx;
             const float Ay = q.qy + Ly;
@@ -647,36 +621,21 @@ mpc_kernel(const KernelParams p)
             const float gv1 = g_d * dt;
             const float gA1 = (g_d * dt2) * 0.5f;
             float Lv = 0.0f, Lth = 0.0f;
-            if (PACKED) {
-                __builtin_amdgcn_wave_barrier();
-                *own4 = make_float4(q.qv, gA1, gv1, v);
-                *own2 = make_float2(q.qth, tau);
-                __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_wave_barrier();
+            *own4 = make_float4(q.qv, gA1, gv1, v);
+            *own2 = make_float2(q.qth, tau);
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int i = 0; i < H - 1; ++i) {
-                    const float4 b = bwd4[-i];             // (qv, gA1, gv1, v) of step j = H-1-i+t, or zeros
-                    const float2 a = bwd2[-i];             // (qth, tau)
-                    const float Av_ = b.x + Lv;
-                    const float gA_ = b.y + Av_ * dt;
-                    const float gv2_ = (-gA_) * fr;
-                    const float gv3_ = (gv2_ * 2.0f) * b.w;
-                    Lv = (b.z + Av_) + gv3_;
-                    const float Ath_ = a.x + Lth;
-                    Lth = Ath_ + a.y;
-                }
-            } else {
-#pragma unroll
-                for (int j = H - 1; j >= 1; --j) {
-                    const float Av_ = lane_value(q.qv, j) + Lv;
-                    const float gA_ = lane_value(gA1, j) + Av_ * dt;
-                    const float gv2_ = (-gA_) * fr;
-                    const float gv3_ = (gv2_ * 2.0f) * lane_value(v, j);
-                    const float Lv_ = (lane_value(gv1, j) + Av_) + gv3_;
-                    const float Ath_ = lane_value(q.qth, j) + Lth;
-                    const float Lth_ = Ath_ + lane_value(tau, j);
-                    Lv = (j > t) ? Lv_ : Lv;
-                    Lth = (j > t) ? Lth_ : Lth;
-                }
+            for (int i = 0; i < H - 1; ++i) {
+                const float4 b = bwd4[-i];             // (qv, gA1, gv1, v) of step j = H-1-i+t, or zeros
+                const float2 a = bwd2[-i];             // (qth, tau)
+                const float Av_ = b.x + Lv;
+                const float gA_ = b.y + Av_ * dt;
+                const float gv2_ = (-gA_) * fr;
+                const float gv3_ = (gv2_ * 2.0f) * b.w;
+                Lv = (b.z + Av_) + gv3_;
+                const float Ath_ = a.x + Lth;
+                Lth = Ath_ + a.y;
             }
             const float Av = q.qv + Lv;
             const float gA = gA1 + Av * dt;
@@ -815,24 +774,14 @@ __global__ void math_kernel(const float *in, float *e, float *s, float *c, long 
 // ---------------------------------------------------------------- launch table
 namespace ocd {
 
-template <int H, int NO, int L, bool PACKED>
-static hipError_t launch_mpc_variant(const KernelParams &p, hipStream_t st);
-
 template <int H, int NO, int L>
 static hipError_t launch_mpc(const KernelParams &p, hipStream_t st)
-{
-    if (p.segs_used == 1) return launch_mpc_variant<H, NO, L, false>(p, st);
-    return launch_mpc_variant<H, NO, L, true>(p, st);
-}
-
-template <int H, int NO, int L, bool PACKED>
-static hipError_t launch_mpc_variant(const KernelParams &p, hipStream_t st)
 {
     using G = Geo<H>;
     const int K = p.K;
     const long long blocks = (p.n_problems + p.segs_used - 1) / p.segs_used;
     const size_t lds = ((size_t)K * G::WAVE_FLOATS + (size_t)2 * K * G::SEL_FLOATS) * sizeof(float);
-    hipLaunchKernelGGL((mpc_kernel<H, NO, L, PACKED>), dim3((unsigned)blocks), dim3(64 * K), lds, st, p);
+    hipLaunchKernelGGL((mpc_kernel<H, NO, L>), dim3((unsigned)blocks), dim3(64 * K), lds, st, p);
     return hipGetLastError();
 }
 

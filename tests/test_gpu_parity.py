@@ -179,6 +179,34 @@ def test_results_do_not_depend_on_packing(oracle, eng_factory, hip, segs):
     assert hip.ocd_set_option(b"nonsense", 1) != 0
 
 
+@pytest.mark.parametrize("segs", [1, 0, 6])
+def test_non_finite_trajectories_bitwise(oracle, eng_factory, hip, segs):
+    """Hard braking drives v negative and the drag term -f*v^2 then runs away to -inf inside the
+    horizon (car_dynamics_step has no speed floor): rewards become -inf, losses +inf, some adjoints
+    NaN.  The kernels must reproduce the oracle through inf and NaN, in both scan variants."""
+    scn = scenarios.finite_horizon(horizon=10, n_iter=30)
+    eng = eng_factory(scn)
+    B = 24
+    ws = _world_states(scn, B, seed=5)
+    ws[:, 0, 2] = np.linspace(-45.0, -5.0, B)          # large negative speeds: overflow after a few steps
+    ws[::5, 0, 2] = 0.8                                # with some ordinary problems mixed in
+    w = np.stack([scenarios.planner_weights_fp32(c) for c in scn.candidate_weights(B, seed=6)])
+    ref = oracle.plan_batch(scn.desc, ws, w)
+    assert np.isinf(ref["all_losses"]).any() or np.isnan(ref["all_losses"]).any()
+    assert hip.ocd_set_option(b"segs_per_wave", segs) == 0
+    try:
+        out = eng.plan_batch(ws, w, want_all=True)
+        ro = eng.rollout_from_state(ws, w, first_step=0, n_steps=8)
+    finally:
+        hip.ocd_set_option(b"segs_per_wave", 0)
+    assert_bitwise(out["all_losses"], ref["all_losses"], "losses")
+    assert_bitwise(out["all_plans"], ref["all_plans"], "plans")
+    assert np.array_equal(out["best_init"], ref["best_init"])
+    rr = oracle.rollout_from_state(scn.desc, ws, w, 0, 8)
+    assert not np.all(np.isfinite(rr["traj"]))          # the WORLD state itself overflows: exact-select fallback
+    assert_bitwise(ro["traj"], rr["traj"], "traj"); assert_bitwise(ro["returns"], rr["returns"], "returns")
+
+
 def test_rollout_episode_range_matches_full(oracle, eng_factory):
     """Sharding contract: any [ep_begin, ep_end) slice equals the same slice of the full run."""
     scn = scenarios.replanning(horizon=5)
