@@ -120,6 +120,7 @@ def load_hip_library(path: Optional[str] = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
+    path = path or os.environ.get("OCD_HIP_LIB") or None      # experiments: an alternative build of the library
     p = path or HIP_LIB_PATH
     if not os.path.exists(p) and path is None:
         # a source-only checkout: compile the library (hipcc cross-compiles gfx950 without a GPU).

@@ -160,6 +160,16 @@ __device__ __forceinline__ BumpGeom bump_geom(float ox, float oy, float hx, floa
 
 struct Q4 { float qx, qy, qv, qth; };
 
+// 1.0f / (float)n for a tie count n in [1, 4]: the correctly rounded quotients as constants
+__device__ __forceinline__ float inv_count(int n)
+{
+    float r = 1.0f;
+    r = (n == 2) ? 0.5f : r;
+    r = (n == 3) ? (1.0f / 3.0f) : r;
+    r = (n == 4) ? 0.25f : r;
+    return r;
+}
+
 // Conservative per-lane tests for the wave-uniform skips of reward_state.
 //  fence:  _f(x - lo) and _f(-x - lo) are both 0 (value AND gradient, math_utils.py:28-31) unless one
 //          argument is > 0; then S = 0/den = 0, the feature is 0*|x| and every adjoint term is +-0.
@@ -281,7 +291,7 @@ __device__ __forceinline__ float reward_state(const ocd_scenario_desc &d, const 
     q.qth = g_sn * cn;
 
     float qx = 0.0f, qy = 0.0f;
-    const float min_share = w_min / (float)ntie_min;
+    const float min_share = inv_count(ntie_min) * w_min;          // (indicator / num_ties) * grad
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         float g = w[1 + l];
@@ -291,7 +301,7 @@ __device__ __forceinline__ float reward_state(const ocd_scenario_desc &d, const 
         qx = qx + g_r * -1.0f;
     }
     if (NO > 0 && do_col) {
-        const float col_share = w_col / (float)ntie_col;
+        const float col_share = inv_count(ntie_col) * w_col;
 #pragma unroll
         for (int j = 0; j < NO; ++j) {
             const float share = (col[j] == pcol) ? col_share : 0.0f;

@@ -20,7 +20,7 @@
  * Reverse mode: the adjoint below is the tape of the forward ops reversed,
  * with TensorFlow's gradient rules (math_grad.py of TF 2.1):
  *   Minimum(x,y): to x iff x<=y;  Maximum(x,y): to x iff x>=y;
- *   Min/Max reduction: (grad*indicator)/num_ties;  Select: chosen branch only;
+ *   Min/Max reduction: (indicator/num_ties)*grad  [math_ops.divide(indicators, num_selected) * grad];  Select: chosen branch only;
  *   RealDiv(x,y): gx = g/y, gy = g*((-x/y)/y);  Pow(x,2): (g*2)*x;
  *   Exp: g*y;  Sin: g*cos(x);  Cos: (-g)*sin(x);  Abs: g*sign(x).
  * Where a value has three or more consumers the order in which TensorFlow
@@ -266,13 +266,13 @@ static float reward_state(const ocd_scenario_desc *d, const float *w,
     float qx = 0.0f, qy = 0.0f;
     for (int l = 0; l < L; ++l) {
         float g = w[1 + l];
-        if (phi[1 + l] == pmin) g = g + w[L + 1] / (float)ntie_min;
+        if (phi[1 + l] == pmin) g = g + (1.0f / (float)ntie_min) * w[L + 1];
         const float g_d2 = g * 10.0f;
         const float g_r = (g_d2 * 2.0f) * rl[l];
         qx = qx + g_r * -1.0f;
     }
     for (int j = 0; j < NO; ++j) {
-        const float share = (col[j] == pcol) ? (w[L + 2] / (float)ntie_col) : 0.0f;
+        const float share = (col[j] == pcol) ? ((1.0f / (float)ntie_col) * w[L + 2]) : 0.0f;
         const float g_bx = share * byv[j];
         const float g_by = share * bxv[j];
         qx = qx + bump_bwd(g_bx, &bx[j]);
