@@ -178,7 +178,7 @@ def main():
         ach_gbs = n_local * nbytes / (kern_ms * 1e-3) / 1e9
         ach_tf = n_local * flops / (kern_ms * 1e-3) / 1e12
         out = {
-            "metric": "MPC episode rollouts/sec at H=10 (one CMA-ES generation's fitness evaluation)",
+            "metric": f"MPC episode rollouts/sec at H={d.horizon} (one CMA-ES generation's fitness evaluation)",
             "value": E * args.steps / dt,
             "unit": "episodes/s",
             "n_gpus": world,

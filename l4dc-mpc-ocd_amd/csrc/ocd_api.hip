@@ -270,13 +270,12 @@ int32_t ocd_rollout_episodes(const ocd_scenario *scn, const float *init_states, 
 {
     if (!scn) return fail(OCD_ERR_INVALID_ARG, "scenario is NULL");
     if (ep_begin == ep_end && ep_begin >= 0) return OCD_OK;
-    int32_t st = need_device();
-    if (st != OCD_OK) return st;
-    const float *plans = nullptr;
-    st = scripted_plans_device(scn, (hipStream_t)hip_stream, &plans);
-    if (st != OCD_OK) return st;
     ocd::KernelParams p;
-    st = rollout_params(scn, init_states, cand_weights, P, N, ep_begin, ep_end, returns_out, traj_out, ctrl_out, plans, p);
+    int32_t st = rollout_params(scn, init_states, cand_weights, P, N, ep_begin, ep_end, returns_out, traj_out, ctrl_out, nullptr, p);
+    if (st != OCD_OK) return st;                          // argument errors first, device errors after
+    st = need_device();
+    if (st != OCD_OK) return st;
+    st = scripted_plans_device(scn, (hipStream_t)hip_stream, &p.other_plans);
     if (st != OCD_OK) return st;
     return launch(scn, p, hip_stream);
 }
@@ -372,14 +371,13 @@ int32_t ocd_time_rollout(const ocd_scenario *scn, const float *init_states, cons
 {
     if (!ms_out || reps < 1) return fail(OCD_ERR_INVALID_ARG, "ms_out is NULL or reps < 1");
     if (!scn) return fail(OCD_ERR_INVALID_ARG, "scenario is NULL");
-    int32_t st = need_device();
-    if (st != OCD_OK) return st;
     hipStream_t stream = (hipStream_t)hip_stream;
-    const float *plans = nullptr;
-    st = scripted_plans_device(scn, stream, &plans);
-    if (st != OCD_OK) return st;
     ocd::KernelParams p;
-    st = rollout_params(scn, init_states, cand_weights, P, N, ep_begin, ep_end, returns_out, nullptr, nullptr, plans, p);
+    int32_t st = rollout_params(scn, init_states, cand_weights, P, N, ep_begin, ep_end, returns_out, nullptr, nullptr, nullptr, p);
+    if (st != OCD_OK) return st;
+    st = need_device();
+    if (st != OCD_OK) return st;
+    st = scripted_plans_device(scn, stream, &p.other_plans);
     if (st != OCD_OK) return st;
     hipEvent_t e0, e1;
     hipError_t e = hipEventCreate(&e0);

@@ -83,3 +83,28 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle_lib" not in text and "libocd_oracle" not in text and "ocd_refmath" not in text, f
+
+
+def test_argument_checks_precede_any_device_work():
+    """Bad arguments are rejected with OCD_ERR_INVALID_ARG and a message, GPU or not."""
+    lib = abi.load_hip_library()
+    scn = scenarios.replanning(horizon=5)
+    h = C.c_void_p()
+    assert lib.ocd_scenario_create(C.byref(scn.desc), C.byref(h)) == abi.OCD_OK
+    buf = np.zeros(64, dtype=np.float32)
+    p = buf.ctypes.data
+    assert lib.ocd_plan_batch(h, None, p, 0, None, p, None, None, None, None, 1, None) == abi.OCD_ERR_INVALID_ARG
+    assert lib.ocd_plan_batch(h, p, None, 0, None, p, None, None, None, None, 1, None) == abi.OCD_ERR_INVALID_ARG
+    assert b"weights" in lib.ocd_last_error()
+    assert lib.ocd_plan_batch(h, p, p, 0, None, p, None, None, None, None, -1, None) == abi.OCD_ERR_INVALID_ARG
+    assert lib.ocd_plan_batch(h, p, p, 0, None, p, None, None, None, None, 0, None) == abi.OCD_OK      # empty batch
+    # episode range outside [0, P*N*S)
+    assert lib.ocd_rollout_episodes(h, p, p, 2, 3, 0, 13, p, None, None, None) == abi.OCD_ERR_INVALID_ARG
+    assert b"episode range" in lib.ocd_last_error()
+    assert lib.ocd_rollout_episodes(h, p, p, 2, 3, 5, 5, p, None, None, None) == abi.OCD_OK               # empty range
+    assert lib.ocd_rollout_from_state(h, p, p, 0, 0, 3, 9, p, None, None, 1, None) == abi.OCD_ERR_INVALID_ARG  # sample 9
+    assert lib.ocd_dynamics_batch(None, p, 0.1, 0.01, 0.2, p, 4, None) == abi.OCD_ERR_INVALID_ARG
+    assert lib.ocd_set_option(b"segs_per_wave", 99) == abi.OCD_ERR_INVALID_ARG
+    assert lib.ocd_set_option(None, 1) == abi.OCD_ERR_INVALID_ARG
+    lib.ocd_scenario_destroy(h)
+    lib.ocd_scenario_destroy(None)                                                                        # no-op
