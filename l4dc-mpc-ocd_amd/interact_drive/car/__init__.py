@@ -1,6 +1,3 @@
-from .car import Car  # noqa: F401
-from .planner_car import PlannerCar  # noqa: F401
-from .linear_reward_car import LinearRewardCar  # noqa: F401
-from .fixed_control_car import FixedControlCar  # noqa: F401
-from .fixed_velocity_car import FixedVelocityCar  # noqa: F401
-from .fixed_plan_car import FixedPlanCar  # noqa: F401
+"""Cars of the reference API (implementation: _cars.py)."""
+from ._cars import (Car, FixedControlCar, FixedPlanCar, FixedVelocityCar, LinearRewardCar,  # noqa: F401
+                    PlannerCar, advance)

@@ -1,21 +1,13 @@
-"""Mirrors experiments/local_opt_scenario.py:6-55."""
-import numpy as np
-
-from .merging import ThreeLaneCarWorld, ThreeLaneTestCar
+"""`local_opt_env` of the reference's experiments/local_opt_scenario.py, built from scenarios.local_opt."""
+from ._build import world_from_scenario
 from ._sampling import make_get_init_state
-from ..car import FixedVelocityCar
+from ... import scenarios
 
 
 def local_opt_env(env_seeds=[1], extra_inits=False, debug=True):
-    get_init_state = make_get_init_state((-0.1, 0.005, (-0.12, -0.08)), (-0.9, 0.04, (-1., -0.8)),
-                                         (1.0, 0.03, (0.9, 1.1)))
-    init_states = [get_init_state(s) for s in env_seeds]
-    world = ThreeLaneCarWorld(visualizer_args=dict(name="Switch Lanes"))
-    weights = np.array([-5, 0., 0., -10, 0, -50, -50])
-    our_car = ThreeLaneTestCar(world, init_states[0], horizon=5, weights=weights / np.linalg.norm(weights),
-                               planner_args=dict(extra_inits=extra_inits), debug=debug)
-    other_car = FixedVelocityCar(world, np.array([0, -0.9, 1., np.pi / 2]), horizon=5, color="gray",
-                                 opacity=0.8, debug=debug)
-    world.add_cars([our_car, other_car])
-    world.reset()
+    scn = scenarios.local_opt(horizon=5, extra_inits=extra_inits)
+    dist = scn.init_dist
+    init_states = [make_get_init_state(dist.x, dist.y, dist.v)(s) for s in env_seeds]
+    our_car, _, world = world_from_scenario(scn, init_states[0], debug=debug,
+                                            visualizer_args=dict(name="Switch Lanes"))
     return our_car, world, init_states

@@ -3,7 +3,7 @@ from typing import Union
 
 import numpy as np
 
-from ..car import FixedVelocityCar, LinearRewardCar, PlannerCar
+from ..car import LinearRewardCar, PlannerCar
 from ..world import CarWorld, ThreeLaneCarWorld  # noqa: F401
 from ... import abi
 
@@ -25,12 +25,10 @@ class ThreeLaneTestCar(LinearRewardCar, PlannerCar):
 
 
 def setup_world():
-    """merging.py:86-99."""
-    world = ThreeLaneCarWorld(visualizer_args=dict(name="Merging", heatmap_show=True))
-    our_car = ThreeLaneTestCar(world, np.array([0, -1.8, 0.8, np.pi / 2]), horizon=5,
-                               weights=np.array([-1, 0., 0., -10., -10., -10, -5]))
-    other_car_1 = FixedVelocityCar(world, np.array([0.1, -1.8, 0.8, np.pi / 2]), horizon=5, color='gray', opacity=0.8)
-    other_car_2 = FixedVelocityCar(world, np.array([0.1, -1.3, 0.8, np.pi / 2]), horizon=5, color='gray', opacity=0.8)
-    world.add_cars([our_car, other_car_1, other_car_2])
-    world.reset()
+    """The merging scenario of experiments/merging.py, built from scenarios.merging."""
+    from ._build import world_from_scenario
+    from ... import scenarios
+    scn = scenarios.merging(horizon=5)
+    our_car, (other_car_1, other_car_2), world = world_from_scenario(
+        scn, scn.default_init, debug=False, visualizer_args=dict(name="Merging", heatmap_show=True))
     return our_car, other_car_1, other_car_2, world

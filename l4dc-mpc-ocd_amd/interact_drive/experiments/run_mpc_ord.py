@@ -10,6 +10,7 @@ import numpy as np
 from .local_opt_scenario import local_opt_env
 from .replanning_world import setup_world as replanning_env
 from ..reward_design.mpc_ord import MPC_ORD, finite_horizon_env
+from ... import scenarios
 
 
 def fmt(arr):
@@ -19,21 +20,19 @@ def fmt(arr):
     return s
 
 
+def _env_entry(factory, scenario_factory, offset_axis, offset):
+    """One row of the reference's `envs` table, with the constants taken from scenarios.py."""
+    scn = scenario_factory()
+    lo, hi = [0., 0., 0., 0.], [0., 0., 0., 0.]
+    lo[offset_axis], hi[offset_axis] = -offset, offset
+    return {'make_env': factory, 'eval_horizon': scn.desc.episode_len, 'init_offset_range': [lo, hi],
+            'num_eval_samples': scn.desc.n_samples, 'tuned_weights': np.array(scn.tuned_weights)}
+
+
 envs = {
-    'local_opt': {
-        'make_env': local_opt_env, 'eval_horizon': 15,
-        'init_offset_range': [[0., -0.1, 0., 0.], [0., 0.1, 0., 0.]], 'num_eval_samples': 1,
-        'tuned_weights': np.array([-0.09686739, 0.25720383, -0.58355971, -0.23075428, -0.41237239,
-                                   -0.4758984, -0.36625558])},
-    'finite_horizon': {
-        'make_env': finite_horizon_env, 'eval_horizon': 15,
-        'init_offset_range': [[-0.1, 0., 0., 0.], [0.1, 0., 0., 0.]], 'num_eval_samples': 1,
-        'tuned_weights': np.array([-0.21963165, -0.01184596, 0.34379187, -0.04687411, -0.06364365,
-                                   -0.54138792, -0.7308079])},
-    'replanning': {
-        'make_env': replanning_env, 'eval_horizon': 20,
-        'init_offset_range': [[-0.05, 0., 0., 0.], [0.05, 0., 0., 0.]], 'num_eval_samples': 2,
-        'tuned_weights': np.array([-0.55899817, -0.4436692, -0.3724511, -0.19964276, -0.5438697, 0.12770043])},
+    'local_opt': _env_entry(local_opt_env, scenarios.local_opt, 1, 0.1),
+    'finite_horizon': _env_entry(finite_horizon_env, scenarios.finite_horizon, 0, 0.1),
+    'replanning': _env_entry(replanning_env, scenarios.replanning, 0, 0.05),
 }
 
 

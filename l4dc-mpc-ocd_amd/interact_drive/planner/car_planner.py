@@ -1,17 +1,15 @@
-"""Mirrors interact_drive/planner/car_planner.py:7-24."""
+"""Planner base types named as in the reference (interact_drive/planner/car_planner.py)."""
 
 
 class CarPlanner(object):
+    """A planner is bound to one car of one world."""
+
     def __init__(self, world, car):
-        self.world = world
-        self.car = car
+        self.world, self.car = world, car
 
     def generate_plan(self):
         raise NotImplementedError
 
 
 class CoordinateAscentPlanner(CarPlanner):
-    """Empty in the reference too (car_planner.py:20-24)."""
-
-    def __init__(self, world, car):
-        super().__init__(world, car)
+    """Declared but never implemented by the reference; kept so that imports resolve."""

@@ -12,9 +12,7 @@ import numpy as np
 
 from .cmaes import CMAES
 from .. import experiments  # noqa: F401
-from ..experiments.merging import ThreeLaneCarWorld, ThreeLaneTestCar
 from ..experiments._sampling import make_get_init_state
-from ..car import FixedVelocityCar
 from .._describe import describe, engine_for
 from ... import sharding
 from ...scenarios import planner_weights_fp32
@@ -170,16 +168,12 @@ class MPC_ORD:
 
 
 def finite_horizon_env(horizon=5, env_seeds=[1], debug=True, extra_inits=False):
-    """mpc_ord.py:162-207."""
-    get_init_state = make_get_init_state((0, 0.04, (-0.1, 0.1)), (-0.9, 0.02, (-0.95, -0.85)),
-                                         (0.8, 0.03, (0.7, 0.9)))
-    init_states = [get_init_state(s) for s in env_seeds]
-    world = ThreeLaneCarWorld(visualizer_args=dict(name="Switch Lanes"))
-    pa = dict(n_iter=200 if horizon == 6 else 100, extra_inits=extra_inits)
-    our_car = ThreeLaneTestCar(world, init_state=init_states[0], horizon=horizon,
-                               weights=np.array([-5, 0., 0., 0., -6., -50, -50]), debug=debug, planner_args=pa)
-    other_car = FixedVelocityCar(world, np.array([0, -0.6, 0.5, np.pi / 2]), horizon=horizon, color="gray",
-                                 opacity=0.8, debug=debug, planner_args=pa)
-    world.add_cars([our_car, other_car])
-    world.reset()
+    """The finite_horizon scenario factory of the reference's mpc_ord.py, built from scenarios.finite_horizon."""
+    from ..experiments._build import world_from_scenario
+    from ... import scenarios
+    scn = scenarios.finite_horizon(horizon=horizon, extra_inits=extra_inits)
+    dist = scn.init_dist
+    init_states = [make_get_init_state(dist.x, dist.y, dist.v)(s) for s in env_seeds]
+    our_car, _, world = world_from_scenario(scn, init_states[0], debug=debug,
+                                            visualizer_args=dict(name="Switch Lanes"))
     return our_car, world, init_states

@@ -14,7 +14,6 @@ world, cars and planner objects of ``interact_drive`` are thin views over it.
 from __future__ import annotations
 
 import dataclasses
-import math
 from typing import Dict, Optional, Sequence, Tuple
 
 import numpy as np
@@ -94,6 +93,8 @@ class Scenario:
     raw_designer_weights: Optional[np.ndarray]
     tuned_weights: Optional[np.ndarray] = None
     default_init: Optional[np.ndarray] = None
+    car_weights: Optional[np.ndarray] = None      # exactly what the reference factory hands to the car constructor
+    planner_args: Optional[dict] = None           # kwargs the factory passes on to NaivePlanner
 
     @property
     def n_features(self) -> int:
@@ -198,7 +199,8 @@ def finite_horizon(horizon: int = 5, extra_inits: bool = False, n_iter: Optional
         InitDistribution((0, 0.04, (-0.1, 0.1)), (-0.9, 0.02, (-0.95, -0.85)), (0.8, 0.03, (0.7, 0.9))),
         raw,
         tuned_weights=np.array([-0.21963165, -0.01184596, 0.34379187, -0.04687411, -0.06364365,
-                                -0.54138792, -0.7308079]))
+                                -0.54138792, -0.7308079]),
+        car_weights=raw, planner_args=dict(n_iter=n_iter, extra_inits=extra_inits))
 
 
 def local_opt(horizon: int = 5, extra_inits: bool = False, n_iter: int = 100) -> Scenario:
@@ -214,7 +216,8 @@ def local_opt(horizon: int = 5, extra_inits: bool = False, n_iter: int = 100) ->
         InitDistribution((-0.1, 0.005, (-0.12, -0.08)), (-0.9, 0.04, (-1., -0.8)), (1.0, 0.03, (0.9, 1.1))),
         raw,
         tuned_weights=np.array([-0.09686739, 0.25720383, -0.58355971, -0.23075428, -0.41237239,
-                                -0.4758984, -0.36625558]))
+                                -0.4758984, -0.36625558]),
+        car_weights=raw / np.linalg.norm(raw), planner_args=dict(extra_inits=extra_inits))
 
 
 def replanning(horizon: int = 5, n_iter: int = 100) -> Scenario:
@@ -240,7 +243,8 @@ def replanning(horizon: int = 5, n_iter: int = 100) -> Scenario:
         "replanning", d,
         InitDistribution((-0.0, 0.02, (-0.005, 0.005)), (-0.9, 0.04, (-1., -0.8)), (1.0, 0.05, (0.8, 1.2))),
         raw,
-        tuned_weights=np.array([-0.55899817, -0.4436692, -0.3724511, -0.19964276, -0.5438697, 0.12770043]))
+        tuned_weights=np.array([-0.55899817, -0.4436692, -0.3724511, -0.19964276, -0.5438697, 0.12770043]),
+        car_weights=raw / np.linalg.norm(raw), planner_args=dict(n_iter=n_iter))
 
 
 def merging(horizon: int = 5, n_iter: int = 100) -> Scenario:
@@ -256,7 +260,7 @@ def merging(horizon: int = 5, n_iter: int = 100) -> Scenario:
     return Scenario(
         "merging", d,
         InitDistribution((0.0, 0.04, (-0.1, 0.1)), (-1.8, 0.04, (-1.9, -1.7)), (0.8, 0.03, (0.7, 0.9))),
-        raw, default_init=np.array([0, -1.8, 0.8, _PI_2]))
+        raw, default_init=np.array([0, -1.8, 0.8, _PI_2]), car_weights=raw)
 
 
 def target_speed_kat(horizon: int, n_iter: int, learning_rate: float, friction: float,
