@@ -37,6 +37,7 @@ struct KernelParams {
     int32_t sample_fixed;      // from_state: which world.reset() outcome (teleported car) applies
     int32_t segs_used;         // trajectories per wavefront (<= 64/H); 0 = let the launcher choose
     int32_t no_skips;          // diagnostics: 1 = always evaluate collision and fence features
+    int32_t scan_mode;         // 0 = automatic, 1 = LDS-window recurrences, 2 = DPP-row recurrences (H <= 16)
 };
 
 // (horizon H, scripted cars NO, lanes L) triples with a compiled planner kernel; L = 0 is the

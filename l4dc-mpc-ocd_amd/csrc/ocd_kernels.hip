@@ -357,6 +357,17 @@ __device__ __forceinline__ bool finite_(float v)
     return (__float_as_uint(v) & 0x7f800000u) != 0x7f800000u;
 }
 
+// DPP moves inside a 16-lane row: lane t receives lane t-1 (row_shr:1) or lane t+1 (row_shl:1); the
+// first / last lane of the row has no source and keeps `old` (bound_ctrl off).  Used by the ROWSCAN
+// variant, where every trajectory owns one row and lane t of the row is horizon step t.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float old, float src)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float from_below(float old, float src) { return dpp_move<0x111>(old, src); }   // row_shr:1
+__device__ __forceinline__ float from_above(float old, float src) { return dpp_move<0x101>(old, src); }   // row_shl:1
+
 // neighbour value from the lane below (lane-1) without touching LDS: DPP wave_shr:1
 __device__ __forceinline__ float lane_below(float v)
 {
@@ -365,7 +376,12 @@ __device__ __forceinline__ float lane_below(float v)
 }
 
 // ---------------------------------------------------------------- the kernel
-template <int H, int NO, int L>
+// ROWSCAN = false: up to 64/H trajectories per wavefront, recurrences through the zero-padded LDS windows
+//                  (big batches: several wavefronts per SIMD hide the LDS round trips).
+// ROWSCAN = true : H <= 16, one trajectory per 16-lane DPP row (up to 4 per wavefront), recurrences by
+//                  row_shr:1 / row_shl:1 moves between neighbouring lanes -- no LDS round trip on the
+//                  critical path of a wavefront that has its SIMD to itself (small batches).
+template <int H, int NO, int L, bool ROWSCAN>
 __global__ void __launch_bounds__(64 * OCD_MAX_CTRL_INITS)
 mpc_kernel(const KernelParams p)
 {
@@ -379,8 +395,10 @@ mpc_kernel(const KernelParams p)
     const int K = p.K;
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
-    const int seg = lane / H;                 // SEGS for the parked tail lanes
-    const int t = lane - seg * H;
+    static_assert(!ROWSCAN || H <= 16, "ROWSCAN keeps a trajectory inside one 16-lane DPP row");
+    const int seg = ROWSCAN ? (lane >> 4) : (lane / H);      // PACKED: G::SEGS for the parked tail lanes
+    const int t = ROWSCAN ? (lane & 15) : (lane - seg * H);
+    const bool in_h = t < H;                                 // ROWSCAN: lanes H..15 of a row idle along
     // zero the pads once (data slots are always written before they are read)
     for (int i = threadIdx.x; i < K * G::WAVE_FLOATS; i += blockDim.x) lds[i] = 0.0f;
     __syncthreads();
@@ -404,8 +422,9 @@ mpc_kernel(const KernelParams p)
     // segs_used <= SEGS trajectories per wavefront: small batches are spread over more wavefronts
     // (one trajectory each) so that the uniform feature skips act per trajectory; big batches pack.
     const long long prob_raw = (long long)blockIdx.x * p.segs_used + seg;
-    const bool live = (seg < p.segs_used) && (prob_raw < p.n_problems);
-    const long long prob = live ? prob_raw : (p.n_problems - 1);     // parked lanes shadow a real problem
+    const bool row_live = (seg < p.segs_used) && (prob_raw < p.n_problems);
+    const bool live = in_h && row_live;
+    const long long prob = row_live ? prob_raw : (p.n_problems - 1); // parked lanes shadow a real problem
 
     const float dt = d.dt, dt2 = d.dt_sq, fr = d.ego_friction, lr = d.learning_rate;
     constexpr int D = L > 0 ? L + 4 : 0;
@@ -543,23 +562,35 @@ mpc_kernel(const KernelParams p)
             const float wdt = w_c * dt;
 
             float v = ev, th = eth;
-            *own2 = make_float2(a_c, wdt);
-            __builtin_amdgcn_wave_barrier();
-            if (ev_finite) {
+            if (ROWSCAN) {
+                // every lane advances its own state by its own control and hands the result to the lane
+                // above; after t rounds lane t holds the state before step t (lane 0 keeps the current state)
 #pragma unroll
                 for (int i = 0; i < H - 1; ++i) {
-                    const float2 aw = fwd2[i];
-                    const float delta = (aw.x - fr * (v * v)) * dt;
-                    v = fma_(delta, mfw[i], v);            // masked (leading) steps see v = ev: delta is finite
-                    th = th + aw.y;
+                    const float v_next = v + (a_c - fr * (v * v)) * dt;
+                    const float th_next = th + wdt;
+                    v = from_below(ev, v_next);
+                    th = from_below(eth, th_next);
                 }
-            } else {                                       // a non-finite current speed: exact selects
+            } else {
+                *own2 = make_float2(a_c, wdt);
+                __builtin_amdgcn_wave_barrier();
+                if (ev_finite) {
 #pragma unroll
-                for (int i = 0; i < H - 1; ++i) {
-                    const float2 aw = fwd2[i];
-                    const float vn_ = v + (aw.x - fr * (v * v)) * dt;
-                    v = (i >= H - 1 - t) ? vn_ : v;
-                    th = th + aw.y;
+                    for (int i = 0; i < H - 1; ++i) {
+                        const float2 aw = fwd2[i];
+                        const float delta = (aw.x - fr * (v * v)) * dt;
+                        v = fma_(delta, mfw[i], v);        // masked (leading) steps see v = ev: delta is finite
+                        th = th + aw.y;
+                    }
+                } else {                                   // a non-finite current speed: exact selects
+#pragma unroll
+                    for (int i = 0; i < H - 1; ++i) {
+                        const float2 aw = fwd2[i];
+                        const float vn_ = v + (aw.x - fr * (v * v)) * dt;
+                        v = (i >= H - 1 - t) ? vn_ : v;
+                        th = th + aw.y;
+                    }
                 }
             }
             // own step t: (v, th) is the state before it
@@ -574,21 +605,37 @@ mpc_kernel(const KernelParams p)
             const float thn = th + wdt;
             float sn, cn;
             sincos_(thn, sn, cn);
-            float s_pre = lane_below(sn);
-            float c_pre = lane_below(cn);
-            s_pre = (t == 0) ? s0 : s_pre;
-            c_pre = (t == 0) ? c0 : c_pre;
+            float s_pre, c_pre;
+            if (ROWSCAN) {
+                s_pre = from_below(s0, sn);                // lane 0 of the row keeps sin/cos of the current heading
+                c_pre = from_below(c0, cn);
+            } else {
+                s_pre = lane_below(sn);
+                c_pre = lane_below(cn);
+                s_pre = (t == 0) ? s0 : s_pre;
+                c_pre = (t == 0) ? c0 : c_pre;
+            }
             const float cd = c_pre * dd;
             const float sd = s_pre * dd;
             float x = ex, y = ey;
-            __builtin_amdgcn_wave_barrier();
-            *own2 = make_float2(cd, sd);
-            __builtin_amdgcn_wave_barrier();
+            if (ROWSCAN) {
+                const float cd_b = from_below(0.0f, cd);   // increment of the step below (0 for lane 0)
+                const float sd_b = from_below(0.0f, sd);
 #pragma unroll
-            for (int i = 0; i < H - 1; ++i) {
-                const float2 c2 = fwd2[i];
-                x = x + c2.x;
-                y = y + c2.y;
+                for (int i = 0; i < H - 1; ++i) {
+                    x = from_below(ex, x) + cd_b;          // lane 0: ex + 0
+                    y = from_below(ey, y) + sd_b;
+                }
+            } else {
+                __builtin_amdgcn_wave_barrier();
+                *own2 = make_float2(cd, sd);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < H - 1; ++i) {
+                    const float2 c2 = fwd2[i];
+                    x = x + c2.x;
+                    y = y + c2.y;
+                }
             }
             const float xn = x + cd;
             const float yn = y + sd;
@@ -601,11 +648,24 @@ mpc_kernel(const KernelParams p)
                 // ===== last pass: objective only (naive_planner.py:154) =====
                 const float r = reward_state<NO, L, false>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, do_col, do_fence);
                 float Rsum = 0.0f;
-                __builtin_amdgcn_wave_barrier();
-                *own2 = make_float2(r, 0.0f);
-                __builtin_amdgcn_wave_barrier();
+                if (ROWSCAN) {
+                    // running sum up the row: after H-1 rounds lane t holds ((0 + r_0) + r_1) + ... + r_t
+                    float S = 0.0f + r;
 #pragma unroll
-                for (int j = 0; j < H; ++j) Rsum = Rsum + data2[j].x;
+                    for (int i = 0; i < H - 1; ++i) {
+                        // the DPP move must execute in ALL lanes (a lane that skipped it would be an
+                        // invalid source for its neighbour): move first, select afterwards
+                        const float below = from_below(0.0f, S);
+                        S = (t == 0) ? S : (below + r);
+                    }
+                    Rsum = S;                              // complete in lane H-1, which publishes the loss
+                } else {
+                    __builtin_amdgcn_wave_barrier();
+                    *own2 = make_float2(r, 0.0f);
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int j = 0; j < H; ++j) Rsum = Rsum + data2[j].x;
+                }
                 loss = -Rsum;
                 break;
             }
@@ -613,14 +673,26 @@ mpc_kernel(const KernelParams p)
 
             // ===== backward =====
             float Lx = 0.0f, Ly = 0.0f;
-            __builtin_amdgcn_wave_barrier();
-            *own2 = make_float2(q.qx, q.qy);
-            __builtin_amdgcn_wave_barrier();
+            if (ROWSCAN) {
+                // idle lanes (t >= H) contribute nothing to the adjoints flowing down the row
+                if (!in_h) { q.qx = 0.0f; q.qy = 0.0f; q.qv = 0.0f; q.qth = 0.0f; }
+                const float qx_a = from_above(0.0f, q.qx); // adjoint term of the step above (0 for the top lane)
+                const float qy_a = from_above(0.0f, q.qy);
 #pragma unroll
-            for (int i = 0; i < H - 1; ++i) {
-                const float2 qq = bwd2[-i];
-                Lx = qq.x + Lx;
-                Ly = qq.y + Ly;
+                for (int i = 0; i < H - 1; ++i) {
+                    Lx = qx_a + from_above(0.0f, Lx);
+                    Ly = qy_a + from_above(0.0f, Ly);
+                }
+            } else {
+                __builtin_amdgcn_wave_barrier();
+                *own2 = make_float2(q.qx, q.qy);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < H - 1; ++i) {
+                    const float2 qq = bwd2[-i];
+                    Lx = qq.x + Lx;
+                    Ly = qq.y + Ly;
+                }
             }
             const float Ax = q.qx + Lx;
             const float Ay = q.qy + Ly;
@@ -631,21 +703,39 @@ mpc_kernel(const KernelParams p)
             const float gv1 = g_d * dt;
             const float gA1 = (g_d * dt2) * 0.5f;
             float Lv = 0.0f, Lth = 0.0f;
-            __builtin_amdgcn_wave_barrier();
-            *own4 = make_float4(q.qv, gA1, gv1, v);
-            *own2 = make_float2(q.qth, tau);
-            __builtin_amdgcn_wave_barrier();
+            if (ROWSCAN) {
+                const float gA1_m = in_h ? gA1 : 0.0f, gv1_m = in_h ? gv1 : 0.0f;
+                const float v_m = in_h ? v : 0.0f, tau_m = in_h ? tau : 0.0f;
+                const float qth_a = from_above(0.0f, q.qth);
+                const float tau_a = from_above(0.0f, tau_m);
 #pragma unroll
-            for (int i = 0; i < H - 1; ++i) {
-                const float4 b = bwd4[-i];             // (qv, gA1, gv1, v) of step j = H-1-i+t, or zeros
-                const float2 a = bwd2[-i];             // (qth, tau)
-                const float Av_ = b.x + Lv;
-                const float gA_ = b.y + Av_ * dt;
-                const float gv2_ = (-gA_) * fr;
-                const float gv3_ = (gv2_ * 2.0f) * b.w;
-                Lv = (b.z + Av_) + gv3_;
-                const float Ath_ = a.x + Lth;
-                Lth = Ath_ + a.y;
+                for (int i = 0; i < H - 1; ++i) {
+                    // what this lane's step sends down to the lane below, from what it has received so far
+                    const float Av_ = q.qv + Lv;
+                    const float gA_ = gA1_m + Av_ * dt;
+                    const float gv2_ = (-gA_) * fr;
+                    const float gv3_ = (gv2_ * 2.0f) * v_m;
+                    const float Lv_down = (gv1_m + Av_) + gv3_;
+                    Lv = from_above(0.0f, Lv_down);
+                    Lth = (qth_a + from_above(0.0f, Lth)) + tau_a;
+                }
+            } else {
+                __builtin_amdgcn_wave_barrier();
+                *own4 = make_float4(q.qv, gA1, gv1, v);
+                *own2 = make_float2(q.qth, tau);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < H - 1; ++i) {
+                    const float4 b = bwd4[-i];             // (qv, gA1, gv1, v) of step j = H-1-i+t, or zeros
+                    const float2 a = bwd2[-i];             // (qth, tau)
+                    const float Av_ = b.x + Lv;
+                    const float gA_ = b.y + Av_ * dt;
+                    const float gv2_ = (-gA_) * fr;
+                    const float gv3_ = (gv2_ * 2.0f) * b.w;
+                    Lv = (b.z + Av_) + gv3_;
+                    const float Ath_ = a.x + Lth;
+                    Lth = Ath_ + a.y;
+                }
             }
             const float Av = q.qv + Lv;
             const float gA = gA1 + Av * dt;
@@ -658,20 +748,23 @@ mpc_kernel(const KernelParams p)
             __builtin_amdgcn_wave_barrier();
         }
 
+        // the objective's horizon sum is complete in every lane (LDS variant) or in lane H-1 (ROWSCAN)
+        const bool has_loss = ROWSCAN ? (t == H - 1) : (t == 0);
         // ---- per-initialisation outputs (plan mode, parity tests) ----
         if (p.mode == OCD_MODE_PLAN && live) {
             if (p.all_plans_out) {
                 float *o = p.all_plans_out + (((size_t)prob * K + wave) * H + t) * 2;
                 o[0] = ua; o[1] = uw;
             }
-            if (p.all_losses_out && t == 0) p.all_losses_out[(size_t)prob * K + wave] = loss;
+            if (p.all_losses_out && has_loss) p.all_losses_out[(size_t)prob * K + wave] = loss;
         }
 
         // ---- first-index argmin over the K initialisations (naive_planner.py:161-162) ----
         float *selb = sel + (size_t)(step & 1) * K * G::SEL_FLOATS;
-        if (t == 0) {
+        {
             float *rec = selb + ((size_t)wave * G::ROWS + seg) * 4;
-            rec[0] = loss; rec[1] = ua; rec[2] = uw;
+            if (has_loss) rec[0] = loss;
+            if (t == 0) { rec[1] = ua; rec[2] = uw; }
         }
         __syncthreads();
         int best = 0;
@@ -784,14 +877,35 @@ __global__ void math_kernel(const float *in, float *e, float *s, float *c, long 
 // ---------------------------------------------------------------- launch table
 namespace ocd {
 
+int choose_segs(int H, long long n_problems, int K);
+
 template <int H, int NO, int L>
-static hipError_t launch_mpc(const KernelParams &p, hipStream_t st)
+static hipError_t launch_mpc(const KernelParams &p_in, hipStream_t st)
 {
     using G = Geo<H>;
+    KernelParams p = p_in;
     const int K = p.K;
-    const long long blocks = (p.n_problems + p.segs_used - 1) / p.segs_used;
     const size_t lds = ((size_t)K * G::WAVE_FLOATS + (size_t)2 * K * G::SEL_FLOATS) * sizeof(float);
-    hipLaunchKernelGGL((mpc_kernel<H, NO, L>), dim3((unsigned)blocks), dim3(64 * K), lds, st, p);
+    // Variant and packing.  scan_mode 1 = LDS windows, 2 = DPP rows, 0 = automatic: rows while they still
+    // give every wavefront a SIMD of its own (256 CUs x 4), else the denser LDS packing.
+    const long long simds = 256LL * 4;
+    bool rows = false;
+    if (H <= 16 && p.scan_mode != 1) {
+        int segs_r = p.segs_used > 0 ? p.segs_used : (int)((p.n_problems * K + simds - 1) / simds);
+        segs_r = segs_r < 1 ? 1 : (segs_r > 4 ? 4 : segs_r);
+        const long long waves_r = ((p.n_problems + segs_r - 1) / segs_r) * K;
+        if (p.scan_mode == 2 || waves_r <= simds + simds / 16) { rows = true; p.segs_used = segs_r; }
+    }
+    if (!rows) {
+        if (p.segs_used <= 0) p.segs_used = choose_segs(H, p.n_problems, K);
+        if (p.segs_used > G::SEGS) p.segs_used = G::SEGS;
+    }
+    const long long blocks = (p.n_problems + p.segs_used - 1) / p.segs_used;
+    if (rows) {
+        if constexpr (H <= 16) hipLaunchKernelGGL((mpc_kernel<H, NO, L, true>), dim3((unsigned)blocks), dim3(64 * K), lds, st, p);
+    } else {
+        hipLaunchKernelGGL((mpc_kernel<H, NO, L, false>), dim3((unsigned)blocks), dim3(64 * K), lds, st, p);
+    }
     return hipGetLastError();
 }
 
@@ -813,9 +927,7 @@ int choose_segs(int H, long long n_problems, int K)
 
 hipError_t launch_mpc_dispatch(int H, int NO, int L, const KernelParams &p_in, hipStream_t st, bool *supported)
 {
-    KernelParams p = p_in;
-    if (p.segs_used <= 0) p.segs_used = choose_segs(H, p.n_problems, p.K);
-    if (p.segs_used > 64 / H) p.segs_used = 64 / H;
+    const KernelParams &p = p_in;
     *supported = true;
     OCD_KERNEL_TABLE(OCD_CASE)
     *supported = false;

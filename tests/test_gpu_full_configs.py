@@ -27,10 +27,15 @@ def _engine(scn):
     return Engine(scn, "cuda:0")
 
 
-def test_config3_every_episode_bitwise(hip, oracle):
+@pytest.mark.parametrize("scan_mode", [1, 2])
+def test_config3_every_episode_bitwise(hip, oracle, scan_mode):
     scn, inits, w32 = _inputs(3)
-    got = _engine(scn).rollout(inits, w32)["returns"]
     ref = oracle.rollout(scn.desc, inits, w32, n_threads=THREADS)["returns"]
+    assert hip.ocd_set_option(b"scan_mode", scan_mode) == 0
+    try:
+        got = _engine(scn).rollout(inits, w32)["returns"]
+    finally:
+        hip.ocd_set_option(b"scan_mode", 0)
     assert got.shape == (64 * 32,) and np.array_equal(got, ref)
 
 
@@ -59,10 +64,12 @@ def test_configs_4_5_full_size(hip, oracle, cfg, n_sampled_ranges):
     perm = rng.permutation(P)
     permuted = eng.rollout(inits, w32[perm])["returns"].reshape(P, N * S)
     assert np.array_equal(permuted, full.reshape(P, N * S)[perm])
-    # packing knob: the one-trajectory-per-wavefront (readlane) variant on EVERY episode
-    assert hip.ocd_set_option(b"segs_per_wave", 1) == 0
-    try:
-        unpacked = eng.rollout(inits, w32)["returns"]
-    finally:
-        hip.ocd_set_option(b"segs_per_wave", 0)
-    assert np.array_equal(unpacked, full), np.nonzero(unpacked != full)[0][:10]
+    # every other launch shape on EVERY episode: one trajectory per wavefront, and (H <= 16) the DPP-row variant
+    shapes = [(1, 1)] + ([(2, 0), (2, 1)] if scn.desc.horizon <= 16 else [])
+    for mode, segs in shapes:
+        assert hip.ocd_set_option(b"scan_mode", mode) == 0 and hip.ocd_set_option(b"segs_per_wave", segs) == 0
+        try:
+            other = eng.rollout(inits, w32)["returns"]
+        finally:
+            hip.ocd_set_option(b"segs_per_wave", 0); hip.ocd_set_option(b"scan_mode", 0)
+        assert np.array_equal(other, full), (mode, segs, np.nonzero(other != full)[0][:10])

@@ -155,6 +155,37 @@ def test_rollout_bitwise(oracle, eng_factory, name, H, P, N):
     assert out["returns"].shape == (P * N * scn.desc.n_samples,)
 
 
+@pytest.mark.parametrize("scan_mode", [1, 2])
+@pytest.mark.parametrize("name,H,n_iter", [("finite_horizon", 10, 40), ("replanning", 15, 25), ("merging", 5, 40),
+                                           ("local_opt", 16, 15), ("finite_horizon", 3, 30)])
+def test_both_scan_variants_bitwise(oracle, eng_factory, hip, scan_mode, name, H, n_iter):
+    """scan_mode 1 (LDS windows) and 2 (DPP row shifts, H <= 16) are two implementations of the same
+    recurrences; both must reproduce the oracle bit for bit, plans, losses and episodes."""
+    scn = scenarios.SCENARIOS[name](horizon=H, n_iter=n_iter)
+    eng = eng_factory(scn)
+    B = 21
+    ws = _world_states(scn, B, seed=H + 3)
+    ws[3, 0, 2] = -40.0                                   # one problem that overflows inside the horizon
+    w = np.stack([scenarios.planner_weights_fp32(c) for c in scn.candidate_weights(B, seed=H + 4)])
+    ref = oracle.plan_batch(scn.desc, ws, w, other_plans=scn.other_plans())
+    inits = scn.init_dist.sample(3, seed=H + 5)
+    rr = oracle.rollout(scn.desc, inits, w[:2], want_traj=True)
+    assert hip.ocd_set_option(b"scan_mode", scan_mode) == 0
+    try:
+        out = eng.plan_batch(ws, w, want_all=True)
+        ro = eng.rollout(inits, w[:2], want_traj=True)
+        hip.ocd_set_option(b"segs_per_wave", 3)          # several trajectories per wavefront as well
+        out3 = eng.plan_batch(ws, w, want_all=True)
+    finally:
+        hip.ocd_set_option(b"scan_mode", 0)
+        hip.ocd_set_option(b"segs_per_wave", 0)
+    for o in (out, out3):
+        assert_bitwise(o["all_losses"], ref["all_losses"], "losses"); assert_bitwise(o["all_plans"], ref["all_plans"], "plans")
+        assert np.array_equal(o["best_init"], ref["best_init"]); assert_bitwise(o["best_loss"], ref["best_loss"], "best loss")
+    assert_bitwise(ro["ctrl"], rr["ctrl"], "controls"); assert_bitwise(ro["traj"], rr["traj"], "traj")
+    assert_bitwise(ro["returns"], rr["returns"], "returns")
+
+
 @pytest.mark.parametrize("segs", [1, 2, 6, 0])
 def test_results_do_not_depend_on_packing(oracle, eng_factory, hip, segs):
     """segs_per_wave (trajectories per wavefront) is a pure performance knob: packed lanes, parked
@@ -165,6 +196,7 @@ def test_results_do_not_depend_on_packing(oracle, eng_factory, hip, segs):
     w = np.stack([scenarios.planner_weights_fp32(c) for c in scn.candidate_weights(29, seed=78)])
     ref = oracle.plan_batch(scn.desc, ws, w)
     assert hip.ocd_set_option(b"segs_per_wave", segs) == 0
+    assert hip.ocd_set_option(b"scan_mode", 1 if segs == 6 else 0) == 0   # 6 per wavefront exists only with LDS windows
     assert hip.ocd_set_option(b"no_feature_skips", segs % 2) == 0       # skips on and off
     try:
         out = eng.plan_batch(ws, w, want_all=True)
@@ -173,6 +205,7 @@ def test_results_do_not_depend_on_packing(oracle, eng_factory, hip, segs):
     finally:
         hip.ocd_set_option(b"segs_per_wave", 0)
         hip.ocd_set_option(b"no_feature_skips", 0)
+        hip.ocd_set_option(b"scan_mode", 0)
     assert_bitwise(out["all_plans"], ref["all_plans"]); assert_bitwise(out["all_losses"], ref["all_losses"])
     rr = oracle.rollout(scn.desc, inits, w[:2], want_traj=True)
     assert_bitwise(ro["traj"], rr["traj"]); assert_bitwise(ro["returns"], rr["returns"])
