@@ -877,8 +877,6 @@ __global__ void math_kernel(const float *in, float *e, float *s, float *c, long 
 // ---------------------------------------------------------------- launch table
 namespace ocd {
 
-int choose_segs(int H, long long n_problems, int K);
-
 template <int H, int NO, int L>
 static hipError_t launch_mpc(const KernelParams &p_in, hipStream_t st)
 {
@@ -886,20 +884,24 @@ static hipError_t launch_mpc(const KernelParams &p_in, hipStream_t st)
     KernelParams p = p_in;
     const int K = p.K;
     const size_t lds = ((size_t)K * G::WAVE_FLOATS + (size_t)2 * K * G::SEL_FLOATS) * sizeof(float);
-    // Variant and packing.  scan_mode 1 = LDS windows, 2 = DPP rows, 0 = automatic: rows while they still
-    // give every wavefront a SIMD of its own (256 CUs x 4), else the denser LDS packing.
-    const long long simds = 256LL * 4;
+    // Variant and packing.  What decides the kernel time of a small or medium batch is how many workgroups
+    // the busiest CU gets (a workgroup is K wavefronts on the CU's 4 SIMDs; a second one doubles up two
+    // SIMDs): measured on 256 CUs, 1024 trajectories take 2.45 ms as 256 workgroups and 3.6 ms as 342.
+    // So: pack just enough trajectories per wavefront for one workgroup per CU; prefer the DPP-row variant
+    // (faster per wavefront, at most 4 trajectories each, H <= 16) when it needs no more rounds of
+    // workgroups than the LDS variant (up to 64/H each), else take the denser LDS packing.
+    // scan_mode 1 / 2 and segs_per_wave force the choice (tests, sweeps).
+    const long long cus = 256;
+    auto ceil_div = [](long long a, long long b) { return (a + b - 1) / b; };
+    auto clampi = [](long long v, long long lo, long long hi) { return (int)(v < lo ? lo : (v > hi ? hi : v)); };
+    const int want = clampi(ceil_div(p.n_problems, cus), 1, 64);
+    const int segs_l = p.segs_used > 0 ? clampi(p.segs_used, 1, G::SEGS) : clampi(want, 1, G::SEGS);
+    const int segs_r = p.segs_used > 0 ? clampi(p.segs_used, 1, 4) : clampi(want, 1, 4);
+    const long long rounds_l = ceil_div(ceil_div(p.n_problems, segs_l), cus);
+    const long long rounds_r = ceil_div(ceil_div(p.n_problems, segs_r), cus);
     bool rows = false;
-    if (H <= 16 && p.scan_mode != 1) {
-        int segs_r = p.segs_used > 0 ? p.segs_used : (int)((p.n_problems * K + simds - 1) / simds);
-        segs_r = segs_r < 1 ? 1 : (segs_r > 4 ? 4 : segs_r);
-        const long long waves_r = ((p.n_problems + segs_r - 1) / segs_r) * K;
-        if (p.scan_mode == 2 || waves_r <= simds + simds / 16) { rows = true; p.segs_used = segs_r; }
-    }
-    if (!rows) {
-        if (p.segs_used <= 0) p.segs_used = choose_segs(H, p.n_problems, K);
-        if (p.segs_used > G::SEGS) p.segs_used = G::SEGS;
-    }
+    if (H <= 16 && p.scan_mode != 1) rows = (p.scan_mode == 2) || rounds_r == 1 || rounds_r < rounds_l;
+    p.segs_used = rows ? segs_r : segs_l;
     const long long blocks = (p.n_problems + p.segs_used - 1) / p.segs_used;
     if (rows) {
         if constexpr (H <= 16) hipLaunchKernelGGL((mpc_kernel<H, NO, L, true>), dim3((unsigned)blocks), dim3(64 * K), lds, st, p);
@@ -910,20 +912,6 @@ static hipError_t launch_mpc(const KernelParams &p_in, hipStream_t st)
 }
 
 #define OCD_CASE(HH, NN, LL) if (H == HH && NO == NN && L == LL) return launch_mpc<HH, NN, LL>(p, st);
-
-// Trajectories per wavefront for a launch of n problems: one per wavefront while that still leaves
-// SIMDs idle (256 CUs x 4 SIMDs), which keeps the uniform feature skips per trajectory; beyond that,
-// pack (up to 64/H) so that the number of wavefronts per SIMD stays minimal.
-int choose_segs(int H, long long n_problems, int K)
-{
-    const int segs_max = 64 / H;
-    const long long waves_unpacked = n_problems * K;
-    const long long budget = 256LL * 4;     // measured (config 3): fewest wavefronts per SIMD wins once every SIMD has one
-    long long segs = (waves_unpacked + budget - 1) / budget;
-    if (segs < 1) segs = 1;
-    if (segs > segs_max) segs = segs_max;
-    return (int)segs;
-}
 
 hipError_t launch_mpc_dispatch(int H, int NO, int L, const KernelParams &p_in, hipStream_t st, bool *supported)
 {
