@@ -13,21 +13,24 @@
 //
 // Mapping.  A workgroup is K wavefronts, K = number of
 // control initialisations (3, or 6 with extra_inits); wavefront k optimises
-// initialisation k.  Inside a wavefront the 64 lanes are cut into SEGS = 64/H
-// segments of H lanes; segment s is one trajectory (one (candidate, init,
-// sample) episode, or one world state in plan mode) and lane t of the segment
-// owns horizon step t: its control u_t, the state before and after step t, the
-// reward features at the post-step state and their adjoint.
+// initialisation k.  Inside a wavefront the lanes are cut into segments; a
+// segment is one trajectory (one (candidate, init, sample) episode, or one
+// world state in plan mode) and lane t of the segment owns horizon step t: its
+// control u_t, the state before and after step t, the reward features at the
+// post-step state and their adjoint.
 //
 // Per SGD iteration the only sequential work is four short recurrences
-// (v/heading forward, x/y forward, x/y adjoint, v/heading adjoint); every lane
-// of a segment runs them redundantly on values the segment exchanged through
-// LDS (one ds_write_b32 per lane, ds_read_b128 broadcasts back), keeping its
-// own prefix by predication.  Everything else -- sincos, the feature
-// exponentials and IEEE divisions, the per-step Jacobian products -- is
-// lane-parallel.  The K wavefronts meet once per control step (one
-// __syncthreads) to pick the best initialisation, then all of them apply the
-// chosen control to the real dynamics.
+// (v/heading forward, x/y forward, x/y adjoint, v/heading adjoint).  Two
+// variants of how a segment's lanes exchange the terms (template ROWSCAN):
+//   LDS windows -- segments of H lanes (64/H per wavefront); every lane writes
+//                  its term into a zero-padded LDS row and reads a lane-shifted
+//                  window, so no step needs a predicate (x + 0 == x);
+//   DPP rows    -- H <= 16, one segment per 16-lane row; H-1 rounds of
+//                  row_shr:1 / row_shl:1 moves between neighbouring lanes.
+// Everything else -- sincos, the feature exponentials and IEEE divisions, the
+// per-step Jacobian products -- is lane-parallel.  The K wavefronts meet once
+// per control step (one __syncthreads) to pick the best initialisation, then
+// all of them apply the chosen control to the real dynamics.
 //
 // Numerics: IEEE binary32, -ffp-contract=off, operation order = the
 // arithmetic contract of DESIGN.md section 3; exp/sin/cos from ocd_devmath.h.
