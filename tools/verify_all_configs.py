@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Exhaustive parity: EVERY episode of BASELINE configs 2-5, HIP path vs CPU oracle, bit for bit.
+(The regular GPU suite checks config 3 completely and configs 4/5 on samples; this is the long form.)
+usage: python tools/verify_all_configs.py [--configs 2,3,4,5] [--threads 16]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", default="2,3,4,5")
+    ap.add_argument("--threads", type=int, default=16)
+    a = ap.parse_args()
+    import oracle_lib
+    from l4dc_mpc_ocd_amd import scenarios
+    from l4dc_mpc_ocd_amd.engine import Engine
+    orc = oracle_lib.load()
+    ok = True
+    for cfg in [int(c) for c in a.configs.split(",")]:
+        scn, inits, cands = scenarios.baseline_config(cfg)
+        w32 = np.stack([scenarios.planner_weights_fp32(c) for c in cands])
+        t0 = time.perf_counter()
+        got = Engine(scn, "cuda:0").rollout(inits, w32)["returns"]
+        t1 = time.perf_counter()
+        ref = np.empty_like(got)
+        E = got.size
+        chunk = 2048
+        for b in range(0, E, chunk):                       # chunked so that progress is visible
+            e = min(E, b + chunk)
+            ref[b:e] = orc.rollout(scn.desc, inits, w32, ep_begin=b, ep_end=e, n_threads=a.threads)["returns"]
+            print(f"  cfg{cfg}: oracle {e}/{E}", flush=True)
+        t2 = time.perf_counter()
+        same = (got == ref) | (np.isnan(got) & np.isnan(ref))
+        nonfinite = int((~np.isfinite(ref)).sum())
+        print(f"cfg{cfg} {scn.name} H={scn.desc.horizon}: {E} episodes, identical {int(same.sum())}/{E} "
+              f"(non-finite returns: {nonfinite}); GPU {t1 - t0:.2f} s incl. setup, oracle {t2 - t1:.1f} s on {a.threads} threads",
+              flush=True)
+        ok &= bool(same.all())
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()
