@@ -120,6 +120,7 @@ const char *ocd_last_error(void);
  *   "segs_per_wave": trajectories packed into one wavefront (1..64/H), 0 = automatic;
  *   "scan_mode": how the horizon recurrences exchange terms: 0 = automatic, 1 = LDS windows,
  *                2 = DPP row shifts (planning horizon <= 16);
+ *   "no_unified_features": 1 = never evaluate fence and collision through the shared exp(-1/u) path;
  *   "no_feature_skips": 1 = evaluate the collision and fence features even where they are
  *                       provably zero (diagnostics; default 0). */
 int32_t ocd_set_option(const char *name, int32_t value);

@@ -36,6 +36,7 @@ thread_local char g_err[512] = "";
 std::atomic<int32_t> g_opt_segs{0};        // "segs_per_wave": 0 = automatic
 std::atomic<int32_t> g_opt_no_skips{0};    // "no_feature_skips": 1 = always evaluate every feature
 std::atomic<int32_t> g_opt_scan_mode{0};   // "scan_mode": 0 automatic, 1 LDS windows, 2 DPP rows
+std::atomic<int32_t> g_opt_no_unify{0};    // "no_unified_features": 1 = fence and collision always evaluated separately
 
 int32_t fail(int32_t status, const char *fmt, ...)
 {
@@ -99,6 +100,7 @@ void base_params(const ocd_scenario *scn, ocd::KernelParams &p)
     p.segs_used = g_opt_segs.load();
     p.no_skips = g_opt_no_skips.load();
     p.scan_mode = g_opt_scan_mode.load();
+    p.no_unify = g_opt_no_unify.load();
 }
 
 int32_t launch(const ocd_scenario *scn, const ocd::KernelParams &p, void *hip_stream)
@@ -140,6 +142,10 @@ int32_t ocd_set_option(const char *name, int32_t value)
     if (std::strcmp(name, "scan_mode") == 0) {
         if (value < 0 || value > 2) return fail(OCD_ERR_INVALID_ARG, "scan_mode %d out of [0,2]", value);
         g_opt_scan_mode.store(value);
+        return OCD_OK;
+    }
+    if (std::strcmp(name, "no_unified_features") == 0) {
+        g_opt_no_unify.store(value ? 1 : 0);
         return OCD_OK;
     }
     if (std::strcmp(name, "no_feature_skips") == 0) {

@@ -38,6 +38,7 @@ struct KernelParams {
     int32_t segs_used;         // trajectories per wavefront (<= 64/H); 0 = let the launcher choose
     int32_t no_skips;          // diagnostics: 1 = always evaluate collision and fence features
     int32_t scan_mode;         // 0 = automatic, 1 = LDS-window recurrences, 2 = DPP-row recurrences (H <= 16)
+    int32_t no_unify;          // diagnostics: 1 = never share the exp(-1/u) units between fence and collision
 };
 
 // (horizon H, scripted cars NO, lanes L) triples with a compiled planner kernel; L = 0 is the

@@ -204,7 +204,8 @@ __device__ __forceinline__ float reward_state(const ocd_scenario_desc &d, const 
                                               float x, float y, float v, float sn, float cn,
                                               const BumpGeom (&bg)[NO > 0 ? NO : 1], Q4 &q,
                                               float *feats /* nullptr or [D] global */,
-                                              const bool do_col = true, const bool do_fence = true)
+                                              const bool do_col = true, const bool do_fence = true,
+                                              const bool unify = false)
 {
     // do_col / do_fence are WAVE-UNIFORM: false only when the caller has proved that, for every live
     // lane, the collision bumps / the fence thresholds are identically zero together with their
@@ -244,31 +245,81 @@ __device__ __forceinline__ float reward_state(const ocd_scenario_desc &d, const 
     float bxv[NO > 0 ? NO : 1], byv[NO > 0 ? NO : 1], col[NO > 0 ? NO : 1];
     float pcol = 0.0f;
     int ntie_col = NO;
-    if (do_col) {
-#pragma unroll
-        for (int j = 0; j < NO; ++j) {
-            bxv[j] = bump_fwd(x, bg[j].cx, bg[j].wx, bx[j]);
-            byv[j] = bump_fwd(y, bg[j].cy, bg[j].wy, by[j]);
-            col[j] = bxv[j] * byv[j];
-            pcol = (j == 0) ? col[0] : max_tf(pcol, col[j]);
-        }
-        ntie_col = 0;
-#pragma unroll
-        for (int j = 0; j < NO; ++j) ntie_col += (col[j] == pcol) ? 1 : 0;
-    }
-
-    // fences = (S(x) + S(-x)) * |x| (merging.py:80-81).  With threshold - width = fence_lo >= 0 the two
-    // arguments x - lo and -x - lo cannot both be positive, and a side whose argument is <= 0 has
-    // F1 = 0 exactly: S = 0/den = 0 and every adjoint term of that side is +-0 (see needs_fence).  So
-    // one smooth_threshold evaluation on the possibly-active side gives S(x) + S(-x) and its gradient
-    // bit for bit (x + 0 = x), at half the divisions and exponentials.
     ThrTape tp_f;
     const bool side_p = (x - d.fence_lo) > 0.0f;
     float Ssum = 0.0f, ax = 0.0f, pf = 0.0f;
-    if (do_fence) {
-        Ssum = thr_fwd(side_p ? x : -x, d.fence_lo, d.fence_width, d.fence_shape, tp_f);
+    // unify (WAVE-UNIFORM, one scripted car): every live lane needs at most ONE of {fence, collision}.
+    // Both are built from two "exp(-1/u + c)" units -- _f(x_diff), _f(width - x_diff) with c = 0, or the
+    // x and y bumps with c = 1 -- so each lane feeds the two units of ITS feature through one shared
+    // instruction stream; the other feature of that lane is exactly 0 with +-0 adjoints (see
+    // needs_fence / needs_collision).  Same operations on the same values as the separate blocks:
+    // m + 0.0f == m, exp(+-0) == 1.
+    bool is_f = false;
+    float uk1 = 0.0f, uk2 = 0.0f;                  // (-m)/u of the two units, for the backward pass
+    if (NO == 1 && unify) {
+        is_f = needs_fence(d, x);
+        // inputs of the fence units
+        const float z = side_p ? x : -x;
+        const float xd = z - d.fence_lo;
+        const bool pos1 = xd > 0.0f;
+        const float uf1 = d.fence_shape * (pos1 ? xd : (0.0f + 0.01f));
+        const float xd2 = d.fence_width - xd;
+        const bool pos2 = xd2 > 0.0f;
+        const float uf2 = d.fence_shape * (pos2 ? xd2 : (0.0f + 0.01f));
+        // inputs of the bump units
+        const float znx = (x - bg[0].cx) / bg[0].wx;
+        const bool condx = (znx * znx) < 1.0f;
+        const float xcx = condx ? znx : 0.0f;
+        const float zny = (y - bg[0].cy) / bg[0].wy;
+        const bool condy = (zny * zny) < 1.0f;
+        const float xcy = condy ? zny : 0.0f;
+        // the two shared units
+        const float u1 = is_f ? uf1 : (1.0f - xcx * xcx);
+        const float u2 = is_f ? uf2 : (1.0f - xcy * xcy);
+        const float addc = is_f ? 0.0f : 1.0f;
+        const float m1 = -1.0f / u1, m2 = -1.0f / u2;
+        const float e1 = exp_le1(m1 + addc), e2 = exp_le1(m2 + addc);
+        if (GRAD) { uk1 = (-m1) / u1; uk2 = (-m2) / u2; }
+        // fence outputs (meaningful on fence lanes)
+        tp_f.t1.pos = pos1; tp_f.t1.m = m1; tp_f.t1.e = e1; tp_f.t1.u = u1;
+        tp_f.t2.pos = pos2; tp_f.t2.m = m2; tp_f.t2.e = e2; tp_f.t2.u = u2;
+        const float F1 = pos1 ? e1 : 0.0f, F2 = pos2 ? e2 : 0.0f;
+        tp_f.den = F1 + F2;
+        tp_f.S = F1 / tp_f.den;
         ax = (x < 0.0f) ? -x : x;
-        pf = Ssum * ax;
+        Ssum = is_f ? tp_f.S : 0.0f;
+        pf = is_f ? (tp_f.S * ax) : 0.0f;
+        // bump outputs (meaningful on the other lanes)
+        bx[0].cond = condx; bx[0].xc = xcx; bx[0].q = u1; bx[0].m = m1; bx[0].e = e1;
+        by[0].cond = condy; by[0].xc = xcy; by[0].q = u2; by[0].m = m2; by[0].e = e2;
+        bxv[0] = condx ? e1 : 0.0f;
+        byv[0] = condy ? e2 : 0.0f;
+        col[0] = is_f ? 0.0f : (bxv[0] * byv[0]);
+        pcol = col[0];
+        ntie_col = 1;
+    } else {
+        if (do_col) {
+#pragma unroll
+            for (int j = 0; j < NO; ++j) {
+                bxv[j] = bump_fwd(x, bg[j].cx, bg[j].wx, bx[j]);
+                byv[j] = bump_fwd(y, bg[j].cy, bg[j].wy, by[j]);
+                col[j] = bxv[j] * byv[j];
+                pcol = (j == 0) ? col[0] : max_tf(pcol, col[j]);
+            }
+            ntie_col = 0;
+#pragma unroll
+            for (int j = 0; j < NO; ++j) ntie_col += (col[j] == pcol) ? 1 : 0;
+        }
+        // fences = (S(x) + S(-x)) * |x| (merging.py:80-81).  With threshold - width = fence_lo >= 0 the two
+        // arguments x - lo and -x - lo cannot both be positive, and a side whose argument is <= 0 has
+        // F1 = 0 exactly: S = 0/den = 0 and every adjoint term of that side is +-0 (see needs_fence).  So
+        // one smooth_threshold evaluation on the possibly-active side gives S(x) + S(-x) and its gradient
+        // bit for bit (x + 0 = x), at half the divisions and exponentials.
+        if (do_fence) {
+            Ssum = thr_fwd(side_p ? x : -x, d.fence_lo, d.fence_width, d.fence_shape, tp_f);
+            ax = (x < 0.0f) ? -x : x;
+            pf = Ssum * ax;
+        }
     }
 
     // reduce_sum(weights * feats), left to right over [phi0, lanes..., min, collision, fences]
@@ -277,8 +328,8 @@ __device__ __forceinline__ float reward_state(const ocd_scenario_desc &d, const 
     for (int l = 0; l < L; ++l) r = r + w[1 + l] * pl[l];
     const float w_min = w[L + 1], w_col = w[L + 2], w_f = w[L + 3];
     r = r + w_min * pmin;
-    if (do_col) r = r + w_col * pcol;      // skipped terms are exactly +-0
-    if (do_fence) r = r + w_f * pf;
+    if (do_col || unify) r = r + w_col * pcol;      // skipped terms are exactly +-0
+    if (do_fence || unify) r = r + w_f * pf;
     if (feats) {
         feats[0] = phi[0];
 #pragma unroll
@@ -303,6 +354,40 @@ __device__ __forceinline__ float reward_state(const ocd_scenario_desc &d, const 
         const float g_r = (g_d2 * 2.0f) * rl[l];
         qx = qx + g_r * -1.0f;
     }
+    if (NO == 1 && unify) {
+        // collision adjoint (zero on fence lanes, where col == pcol == 0 and both bump values are gated)
+        const float share = (col[0] == pcol) ? (inv_count(1) * w_col) : 0.0f;
+        const float g_bx = is_f ? 0.0f : (share * byv[0]);
+        const float g_by = is_f ? 0.0f : (share * bxv[0]);
+        {
+            const float g_e = bx[0].cond ? g_bx : 0.0f;
+            const float g_q = (g_e * bx[0].e) * uk1;
+            const float g_xc = ((-g_q) * 2.0f) * bx[0].xc;
+            const float g_zn = bx[0].cond ? g_xc : 0.0f;
+            const float cx_term = g_zn / bg[0].wx;
+            qx = is_f ? qx : (qx + cx_term);
+        }
+        {
+            const float g_e = by[0].cond ? g_by : 0.0f;
+            const float g_q = (g_e * by[0].e) * uk2;
+            const float g_xc = ((-g_q) * 2.0f) * by[0].xc;
+            const float g_zn = by[0].cond ? g_xc : 0.0f;
+            const float cy_term = g_zn / bg[0].wy;
+            qy = is_f ? qy : (qy + cy_term);
+        }
+        // fence adjoint (skipped on the other lanes, where it is +-0)
+        const float g_Ssum = w_f * ax;
+        const float g_ax = w_f * Ssum;
+        const float g_F1a = g_Ssum / tp_f.den;
+        const float g_den = g_Ssum * ((-tp_f.S) / tp_f.den);
+        const float ga = f_bwd(g_F1a, d.fence_shape, tp_f.t1, uk1);
+        const float gb = f_bwd(g_den, d.fence_shape, tp_f.t1, uk1);
+        const float gc = f_bwd(g_den, d.fence_shape, tp_f.t2, uk2);
+        const float g_z = (ga + gb) + (-gc);
+        const float sgn = (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f);
+        const float qx_f = (qx + (side_p ? g_z : -g_z)) + g_ax * sgn;
+        qx = is_f ? qx_f : qx;
+    } else {
     if (NO > 0 && do_col) {
         const float col_share = inv_count(ntie_col) * w_col;
 #pragma unroll
@@ -321,6 +406,7 @@ __device__ __forceinline__ float reward_state(const ocd_scenario_desc &d, const 
         qx = qx + (side_p ? g_z : -g_z);
         const float sgn = (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f);
         qx = qx + g_ax * sgn;
+    }
     }
     q.qx = qx; q.qy = qy;
     return r;
@@ -647,9 +733,12 @@ mpc_kernel(const KernelParams p)
             constexpr bool lane_feats = L > 0;
             const bool do_fence = lane_feats && (p.no_skips || __ballot(live && needs_fence(d, xn)) != 0ull);
             const bool do_col = lane_feats && (NO > 0) && (p.no_skips || __ballot(live && needs_collision<NO>(xn, yn, bg)) != 0ull);
+            // both needed, but by disjoint sets of lanes: one shared evaluation (see reward_state)
+            const bool unify = (NO == 1) && lane_feats && do_col && do_fence && !p.no_unify &&
+                               (__ballot(live && needs_fence(d, xn) && needs_collision<NO>(xn, yn, bg)) == 0ull);
             if (it == n_iter) {
                 // ===== last pass: objective only (naive_planner.py:154) =====
-                const float r = reward_state<NO, L, false>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, do_col, do_fence);
+                const float r = reward_state<NO, L, false>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, do_col, do_fence, unify);
                 float Rsum = 0.0f;
                 if (ROWSCAN) {
                     // running sum up the row: after H-1 rounds lane t holds ((0 + r_0) + r_1) + ... + r_t
@@ -672,7 +761,7 @@ mpc_kernel(const KernelParams p)
                 loss = -Rsum;
                 break;
             }
-            reward_state<NO, L, true>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, do_col, do_fence);
+            reward_state<NO, L, true>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, do_col, do_fence, unify);
 
             // ===== backward =====
             float Lx = 0.0f, Ly = 0.0f;

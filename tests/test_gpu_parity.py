@@ -198,6 +198,7 @@ def test_results_do_not_depend_on_packing(oracle, eng_factory, hip, segs):
     assert hip.ocd_set_option(b"segs_per_wave", segs) == 0
     assert hip.ocd_set_option(b"scan_mode", 1 if segs == 6 else 0) == 0   # 6 per wavefront exists only with LDS windows
     assert hip.ocd_set_option(b"no_feature_skips", segs % 2) == 0       # skips on and off
+    assert hip.ocd_set_option(b"no_unified_features", (segs // 2) % 2) == 0   # shared exp(-1/u) path on and off
     try:
         out = eng.plan_batch(ws, w, want_all=True)
         inits = scn.init_dist.sample(5, seed=79)
@@ -205,6 +206,7 @@ def test_results_do_not_depend_on_packing(oracle, eng_factory, hip, segs):
     finally:
         hip.ocd_set_option(b"segs_per_wave", 0)
         hip.ocd_set_option(b"no_feature_skips", 0)
+        hip.ocd_set_option(b"no_unified_features", 0)
         hip.ocd_set_option(b"scan_mode", 0)
     assert_bitwise(out["all_plans"], ref["all_plans"]); assert_bitwise(out["all_losses"], ref["all_losses"])
     rr = oracle.rollout(scn.desc, inits, w[:2], want_traj=True)

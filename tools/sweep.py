@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--pop-scale", type=int, default=1, help="multiply the population (bigger batches)")
     ap.add_argument("--no-skips", type=int, default=0)
+    ap.add_argument("--no-unify", type=int, default=0)
     ap.add_argument("--scan-mode", default="0", help="comma list of scan modes: 0 auto, 1 LDS windows, 2 DPP rows")
     a = ap.parse_args()
     import torch
@@ -34,6 +35,7 @@ def main():
         E = P * N * S
         ret = torch.empty(E, dtype=torch.float32, device="cuda")
         eng.lib.ocd_set_option(b"no_feature_skips", a.no_skips)
+        eng.lib.ocd_set_option(b"no_unified_features", a.no_unify)
         for mode in [int(m) for m in a.scan_mode.split(",")]:
             if mode == 2 and c["horizon"] > 16:
                 continue
