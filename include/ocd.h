@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define OCD_ABI_VERSION 1
+#define OCD_ABI_VERSION 2
 
 #define OCD_MAX_CARS 4      /* ego + up to 3 scripted cars                    */
 #define OCD_MAX_OTHERS 3
@@ -82,7 +82,8 @@ typedef struct ocd_scenario_desc {
     int32_t episode_len;        /* T, MPC_ORD.designer_horizon (mpc_ord.py:95) */
     int32_t n_samples;          /* S, MPC_ORD.num_samples (mpc_ord.py:87) */
     int32_t teleport_step;      /* ReplanningCarWorld.critical_t (replanning_world.py:18,32); 0 = never */
-    int32_t teleport_car[OCD_MAX_SAMPLES]; /* car index moved away in sample s (replanning_world.py:24-27,33) */
+    int32_t teleport_car[OCD_MAX_SAMPLES]; /* car index moved away by the i-th reset of the teleport cycle
+                                            * (replanning_world.py:24-27,33); see teleport_period */
     float teleport_state[4];    /* (10,0,0,0) (replanning_world.py:34) */
 
     float dt;                   /* CarWorld.dt (world.py:19) */
@@ -105,6 +106,17 @@ typedef struct ocd_scenario_desc {
     float other_default[OCD_MAX_OTHERS][2];   /* FixedPlanCar.default_control / FixedControlCar.control */
 
     float designer_weights[OCD_MAX_FEATURES]; /* MPC_ORD.designer_weights, fp32, already normalised (mpc_ord.py:24) */
+
+    /* ---- ABI 2 ---- */
+    /* ReplanningCarWorld.reset() toggles the removed car on EVERY reset (replanning_world.py:24-27), so
+     * in a sequential evaluation the episode with flat index e is reset number reset_phase + e and
+     * loses car teleport_car[(reset_phase + e) % teleport_period] ("reset_phase": ocd_scenario_set_option).
+     * 0 = index teleport_car by the sample s instead (identical whenever n_samples == teleport_period). */
+    int32_t teleport_period;    /* in [0, OCD_MAX_SAMPLES]; 2 for ReplanningCarWorld */
+    /* What PlannerCar._get_next_control assumes for a scripted car beyond its plan when check_plans is
+     * set (planner_car.py:66-75): default_control if the car has a plan and a default_control, else
+     * (0, 0) -- also for a FixedControlCar, whose REAL control is other_default. */
+    float other_assumed_default[OCD_MAX_OTHERS][2];
 } ocd_scenario_desc;
 
 typedef struct ocd_scenario ocd_scenario; /* opaque: validated descriptor + device-side constants */
@@ -116,20 +128,43 @@ int32_t ocd_device_count(void);
 /* Thread-local description of the last error returned on this thread. */
 const char *ocd_last_error(void);
 
-/* Process-wide tuning knobs; results never depend on them.
- *   "segs_per_wave": trajectories packed into one wavefront (1..64/H), 0 = automatic;
- *   "scan_mode": how the horizon recurrences exchange terms: 0 = automatic, 1 = LDS windows,
- *                2 = DPP row shifts (planning horizon <= 16);
- *   "no_unified_features": 1 = never evaluate fence and collision through the shared exp(-1/u) path;
- *   "no_feature_skips": 1 = evaluate the collision and fence features even where they are
- *                       provably zero (diagnostics; default 0). */
-int32_t ocd_set_option(const char *name, int32_t value);
-
 /* Validate a descriptor and build the handle the kernels read their constants
  * from.  Replaces the reference's scenario factories + NaivePlanner.__init__
- * (naive_planner.py:19-30, planner_car.py:49-52). */
+ * (naive_planner.py:19-30, planner_car.py:49-52).  Any planning horizon in
+ * [1, OCD_MAX_HORIZON], 0..OCD_MAX_OTHERS scripted cars and 1..OCD_MAX_LANES lanes run. */
 int32_t ocd_scenario_create(const ocd_scenario_desc *desc, ocd_scenario **out);
 void ocd_scenario_destroy(ocd_scenario *scn);
+
+/* Per-handle options (no process-global state; set them before launching on other threads).
+ * Tuning knobs -- results never depend on them:
+ *   "segs_per_wave": trajectories packed into one wavefront, 0 = automatic;
+ *   "scan_mode": how the horizon recurrences exchange terms and where the K control initialisations
+ *                live: 0 = automatic, 1 = LDS windows (K wavefronts per workgroup), 2 = DPP row shifts
+ *                (H <= 16, K wavefronts per workgroup), 3 = all K initialisations in one wavefront
+ *                (K*H <= 64, wavefront shifts, no workgroup barrier); a mode the scenario cannot use
+ *                falls back to 1;
+ *   "no_unified_features": 1 = never evaluate a lane's single active feature through the shared path;
+ *   "no_feature_skips": 1 = evaluate the collision and fence features even where they are provably
+ *                       zero (diagnostics; default 0).
+ * Episode bookkeeping:
+ *   "reset_phase": world.reset() calls made before episode 0 of the next ocd_rollout_episodes batch
+ *                  (see ocd_scenario_desc.teleport_period); default 0. */
+int32_t ocd_scenario_set_option(ocd_scenario *scn, const char *name, int32_t value);
+
+/*
+ * Terminal value of the planner: NaivePlanner(leaf_evaluation=ValueFeature(...).interpolate_value(t))
+ * (naive_planner.py:20,69-70; reward_design/value_interpolation.py:28-61).  When set, the reward of
+ * the LAST horizon step is the trilinear interpolation of `values` at the coarse state
+ * proj(world_state) instead of car.reward_fn: proj_kind 0 = (x, y, v) of the planning car,
+ * 1 = (x, y, v * sin(heading)) (the coarse state of coarse_value_iteration.py:117-124).  NaN outside
+ * [grid[0], grid[-1]] in any dimension, like the reference.
+ *   grid0/1/2 [n0]/[n1]/[n2]  ascending cell boundaries (ValueFeature.disc_grid), HOST pointers
+ *   values    [n0, n1, n2]    one time slice of v_grids (v_grids[t]), HOST pointer
+ * The handle copies the table (to every device it launches on).  values == NULL removes it.
+ */
+int32_t ocd_scenario_set_leaf_value(ocd_scenario *scn, const float *grid0, int32_t n0,
+                                    const float *grid1, int32_t n1, const float *grid2, int32_t n2,
+                                    const float *values, int32_t proj_kind);
 
 /*
  * One receding-horizon plan for each of B independent world states.
@@ -201,6 +236,23 @@ int32_t ocd_rollout_from_state(const ocd_scenario *scn, const float *world_state
                                int32_t first_step, int32_t n_steps, int32_t sample,
                                float *returns_out, float *traj_out, float *ctrl_out,
                                int64_t B, void *hip_stream);
+
+/*
+ * The planner's objective and its gradient for caller-supplied controls: replaces
+ * NaivePlanner.reward_func(init_state, controls, other_controls, weights) (naive_planner.py:33-77)
+ * and tf.GradientTape over it (naive_planner.py:124-125,153).
+ *   world_state [B, C, 4]; weights [B, D] or [D] (weights_per_problem);
+ *   controls    [B, H, 2]  (clipped inside the dynamics exactly like the reference);
+ *   other_plans [C-1, H, 2] or NULL (constant-velocity model);
+ *   reward_out  [B]        R = sum over the horizon of car.reward_fn (or the terminal value)  (may be NULL)
+ *   grad_out    [B, H, 2]  dR/dcontrols                                                      (may be NULL)
+ *   traj_out    [B, H, 4]  the planning car's state after each horizon step                   (may be NULL)
+ */
+int32_t ocd_mpc_reward_batch(const ocd_scenario *scn, const float *world_state,
+                             const float *weights, int32_t weights_per_problem,
+                             const float *controls, const float *other_plans,
+                             float *reward_out, float *grad_out, float *traj_out,
+                             int64_t B, void *hip_stream);
 
 /*
  * car_dynamics_step / next_car_state for B (state, control) pairs

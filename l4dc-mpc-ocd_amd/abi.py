@@ -11,7 +11,7 @@ import ctypes as C
 import os
 from typing import Optional
 
-OCD_ABI_VERSION = 1
+OCD_ABI_VERSION = 2
 OCD_MAX_CARS = 4
 OCD_MAX_OTHERS = 3
 OCD_MAX_LANES = 4
@@ -65,6 +65,8 @@ class ScenarioDesc(C.Structure):
         ("other_plan", ((C.c_float * 2) * OCD_MAX_PLAN) * OCD_MAX_OTHERS),
         ("other_default", (C.c_float * 2) * OCD_MAX_OTHERS),
         ("designer_weights", C.c_float * OCD_MAX_FEATURES),
+        ("teleport_period", C.c_int32),
+        ("other_assumed_default", (C.c_float * 2) * OCD_MAX_OTHERS),
     ]
 
     @property
@@ -84,15 +86,18 @@ HIP_SYMBOLS = [
     ("ocd_abi_version", C.c_int32, []),
     ("ocd_device_count", C.c_int32, []),
     ("ocd_last_error", C.c_char_p, []),
-    ("ocd_set_option", C.c_int32, [C.c_char_p, C.c_int32]),
     ("ocd_scenario_create", C.c_int32, [C.POINTER(ScenarioDesc), C.POINTER(_VP)]),
     ("ocd_scenario_destroy", None, [_VP]),
+    ("ocd_scenario_set_option", C.c_int32, [_VP, C.c_char_p, C.c_int32]),
+    ("ocd_scenario_set_leaf_value", C.c_int32, [_VP, _F, C.c_int32, _F, C.c_int32, _F, C.c_int32, _F, C.c_int32]),
     ("ocd_plan_batch", C.c_int32,
      [_VP, _VP, _VP, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, _VP]),
     ("ocd_rollout_episodes", C.c_int32,
      [_VP, _VP, _VP, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _VP, _VP, _VP, _VP]),
     ("ocd_rollout_from_state", C.c_int32,
      [_VP, _VP, _VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _VP, _VP, _VP, C.c_int64, _VP]),
+    ("ocd_mpc_reward_batch", C.c_int32,
+     [_VP, _VP, _VP, C.c_int32, _VP, _VP, _VP, _VP, _VP, C.c_int64, _VP]),
     ("ocd_dynamics_batch", C.c_int32, [_VP, _VP, C.c_float, C.c_float, C.c_float, _VP, C.c_int64, _VP]),
     ("ocd_reward_batch", C.c_int32, [_VP, _VP, _VP, _VP, _VP, C.c_int64, _VP]),
     ("ocd_debug_math", C.c_int32, [_VP, _VP, _VP, _VP, C.c_int64, _VP]),

@@ -17,26 +17,30 @@
 #define OCD_MAX_DEVICES 16
 #include <mutex>
 
+#include <vector>
+
 struct ocd_scenario {
     ocd_scenario_desc desc;
     int32_t K;
     int32_t D;
+    // per-handle options (ocd_scenario_set_option)
+    int32_t opt_segs = 0, opt_no_skips = 0, opt_scan_mode = 0, opt_no_unify = 0, opt_reset_phase = 0;
     // The planner's fixed view of the scripted cars' plans (planner_car.py:58-80:
-    // plan[j] from index 0, then default_control) is a scenario constant; rollouts
+    // plan[j] from index 0, then the assumed default) is a scenario constant; rollouts
     // read it from a small device buffer owned by the handle, one per device.
     std::mutex mu;
     float *dev_plans[OCD_MAX_DEVICES];
+    // terminal-value table (ocd_scenario_set_leaf_value): host copy + one device copy per device
+    std::vector<float> leaf_host;          // [n0 + n1 + n2 grid values | n0*n1*n2 table values]
+    int32_t leaf_n[3] = {0, 0, 0};
+    int32_t leaf_proj = 0;
+    float *dev_leaf[OCD_MAX_DEVICES];
+    int32_t n_cus[OCD_MAX_DEVICES];
 };
-
-#include <atomic>
 
 namespace {
 
 thread_local char g_err[512] = "";
-std::atomic<int32_t> g_opt_segs{0};        // "segs_per_wave": 0 = automatic
-std::atomic<int32_t> g_opt_no_skips{0};    // "no_feature_skips": 1 = always evaluate every feature
-std::atomic<int32_t> g_opt_scan_mode{0};   // "scan_mode": 0 automatic, 1 LDS windows, 2 DPP rows
-std::atomic<int32_t> g_opt_no_unify{0};    // "no_unified_features": 1 = fence and collision always evaluated separately
 
 int32_t fail(int32_t status, const char *fmt, ...)
 {
@@ -70,8 +74,10 @@ int32_t validate(const ocd_scenario_desc *d)
     for (int j = 0; j < d->n_cars - 1; ++j)
         if (d->other_plan_len[j] < 0 || d->other_plan_len[j] > OCD_MAX_PLAN)
             return fail(OCD_ERR_INVALID_ARG, "other_plan_len[%d] = %d out of [0,%d]", j, d->other_plan_len[j], OCD_MAX_PLAN);
+    if (d->teleport_period < 0 || d->teleport_period > OCD_MAX_SAMPLES)
+        return fail(OCD_ERR_INVALID_ARG, "teleport_period %d out of [0,%d]", d->teleport_period, OCD_MAX_SAMPLES);
     if (d->teleport_step > 0)
-        for (int s = 0; s < d->n_samples; ++s)
+        for (int s = 0; s < (d->teleport_period > 0 ? d->teleport_period : d->n_samples); ++s)
             if (d->teleport_car[s] >= d->n_cars)
                 return fail(OCD_ERR_INVALID_ARG, "teleport_car[%d] = %d >= n_cars", s, d->teleport_car[s]);
     if (!(d->dt > 0.0f)) return fail(OCD_ERR_INVALID_ARG, "dt must be > 0");
@@ -91,25 +97,64 @@ int32_t need_device()
     return OCD_OK;
 }
 
+// device-side constants of the handle on the current device: compute-unit count, terminal-value table
+int32_t device_state(const ocd_scenario *scn_c, hipStream_t st, ocd::KernelParams &p)
+{
+    ocd_scenario *scn = const_cast<ocd_scenario *>(scn_c);
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return hip_fail(e, "hipGetDevice");
+    if (dev < 0 || dev >= OCD_MAX_DEVICES) return fail(OCD_ERR_UNSUPPORTED, "device ordinal %d >= %d", dev, OCD_MAX_DEVICES);
+    std::lock_guard<std::mutex> lock(scn->mu);
+    if (scn->n_cus[dev] == 0) {
+        int n = 0;
+        e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess || n <= 0) return hip_fail(e, "hipDeviceGetAttribute(multiprocessor count)");
+        scn->n_cus[dev] = n;
+    }
+    p.n_cus = scn->n_cus[dev];
+    if (!scn->leaf_host.empty()) {
+        if (!scn->dev_leaf[dev]) {
+            const size_t bytes = scn->leaf_host.size() * sizeof(float);
+            float *buf = nullptr;
+            e = hipMalloc(&buf, bytes);
+            if (e != hipSuccess) return hip_fail(e, "hipMalloc(terminal-value table)");
+            e = hipMemcpyAsync(buf, scn->leaf_host.data(), bytes, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) { (void)hipFree(buf); return hip_fail(e, "hipMemcpy(terminal-value table)"); }
+            scn->dev_leaf[dev] = buf;
+        }
+        const int ng = scn->leaf_n[0] + scn->leaf_n[1] + scn->leaf_n[2];
+        p.leaf.grid = scn->dev_leaf[dev];
+        p.leaf.values = scn->dev_leaf[dev] + ng;
+        for (int k = 0; k < 3; ++k) p.leaf.n[k] = scn->leaf_n[k];
+        p.leaf.proj_kind = scn->leaf_proj;
+    }
+    return OCD_OK;
+}
+
 void base_params(const ocd_scenario *scn, ocd::KernelParams &p)
 {
     std::memset(&p, 0, sizeof(p));
     p.d = scn->desc;
     p.K = scn->K;
     p.S = scn->desc.n_samples;
-    p.segs_used = g_opt_segs.load();
-    p.no_skips = g_opt_no_skips.load();
-    p.scan_mode = g_opt_scan_mode.load();
-    p.no_unify = g_opt_no_unify.load();
+    p.segs_used = scn->opt_segs;
+    p.no_skips = scn->opt_no_skips;
+    p.scan_mode = scn->opt_scan_mode;
+    p.no_unify = scn->opt_no_unify;
+    p.reset_phase = scn->opt_reset_phase;
 }
 
-int32_t launch(const ocd_scenario *scn, const ocd::KernelParams &p, void *hip_stream)
+int32_t launch(const ocd_scenario *scn, ocd::KernelParams &p, void *hip_stream)
 {
+    int32_t ds = device_state(scn, (hipStream_t)hip_stream, p);
+    if (ds != OCD_OK) return ds;
     bool supported = false;
     const int L = scn->desc.reward_kind == OCD_REWARD_LANE_FEATURES ? scn->desc.n_lanes : 0;
     hipError_t e = ocd::launch_mpc_dispatch(scn->desc.horizon, scn->desc.n_cars - 1, L, p, (hipStream_t)hip_stream, &supported);
     if (!supported)
-        return fail(OCD_ERR_UNSUPPORTED, "no compiled kernel for horizon %d with %d scripted cars and %d lanes (see OCD_KERNEL_TABLE)",
+        return fail(OCD_ERR_UNSUPPORTED, "no compiled kernel for horizon %d with %d scripted cars and %d lanes (see OCD_PAIR_TABLE)",
                     scn->desc.horizon, scn->desc.n_cars - 1, L);
     if (e != hipSuccess) return hip_fail(e, "mpc_kernel launch");
     return OCD_OK;
@@ -131,28 +176,56 @@ int32_t ocd_device_count(void)
 
 const char *ocd_last_error(void) { return g_err; }
 
-int32_t ocd_set_option(const char *name, int32_t value)
+int32_t ocd_scenario_set_option(ocd_scenario *scn, const char *name, int32_t value)
 {
+    if (!scn) return fail(OCD_ERR_INVALID_ARG, "scenario is NULL");
     if (!name) return fail(OCD_ERR_INVALID_ARG, "option name is NULL");
     if (std::strcmp(name, "segs_per_wave") == 0) {
         if (value < 0 || value > 64) return fail(OCD_ERR_INVALID_ARG, "segs_per_wave %d out of [0,64]", value);
-        g_opt_segs.store(value);
+        scn->opt_segs = value;
         return OCD_OK;
     }
     if (std::strcmp(name, "scan_mode") == 0) {
-        if (value < 0 || value > 2) return fail(OCD_ERR_INVALID_ARG, "scan_mode %d out of [0,2]", value);
-        g_opt_scan_mode.store(value);
+        if (value < 0 || value > 3) return fail(OCD_ERR_INVALID_ARG, "scan_mode %d out of [0,3]", value);
+        scn->opt_scan_mode = value;
         return OCD_OK;
     }
-    if (std::strcmp(name, "no_unified_features") == 0) {
-        g_opt_no_unify.store(value ? 1 : 0);
-        return OCD_OK;
-    }
-    if (std::strcmp(name, "no_feature_skips") == 0) {
-        g_opt_no_skips.store(value ? 1 : 0);
+    if (std::strcmp(name, "no_unified_features") == 0) { scn->opt_no_unify = value ? 1 : 0; return OCD_OK; }
+    if (std::strcmp(name, "no_feature_skips") == 0) { scn->opt_no_skips = value ? 1 : 0; return OCD_OK; }
+    if (std::strcmp(name, "reset_phase") == 0) {
+        if (value < 0) return fail(OCD_ERR_INVALID_ARG, "reset_phase %d < 0", value);
+        scn->opt_reset_phase = value;
         return OCD_OK;
     }
     return fail(OCD_ERR_INVALID_ARG, "unknown option '%s'", name);
+}
+
+int32_t ocd_scenario_set_leaf_value(ocd_scenario *scn, const float *grid0, int32_t n0,
+                                    const float *grid1, int32_t n1, const float *grid2, int32_t n2,
+                                    const float *values, int32_t proj_kind)
+{
+    if (!scn) return fail(OCD_ERR_INVALID_ARG, "scenario is NULL");
+    std::lock_guard<std::mutex> lock(scn->mu);
+    for (int i = 0; i < OCD_MAX_DEVICES; ++i)
+        if (scn->dev_leaf[i]) { (void)hipFree(scn->dev_leaf[i]); scn->dev_leaf[i] = nullptr; }
+    scn->leaf_host.clear();
+    if (!values) return OCD_OK;
+    if (!grid0 || !grid1 || !grid2) return fail(OCD_ERR_INVALID_ARG, "a grid pointer is NULL");
+    if (proj_kind != 0 && proj_kind != 1) return fail(OCD_ERR_INVALID_ARG, "proj_kind %d not in {0,1}", proj_kind);
+    const int32_t n[3] = {n0, n1, n2};
+    const float *gr[3] = {grid0, grid1, grid2};
+    for (int k = 0; k < 3; ++k) {
+        if (n[k] < 2 || n[k] > 4096) return fail(OCD_ERR_INVALID_ARG, "grid %d has %d points (need 2..4096)", k, n[k]);
+        for (int i = 1; i < n[k]; ++i)
+            if (!(gr[k][i] > gr[k][i - 1])) return fail(OCD_ERR_INVALID_ARG, "grid %d is not strictly ascending at %d", k, i);
+    }
+    const size_t nv = (size_t)n0 * n1 * n2;
+    scn->leaf_host.reserve((size_t)n0 + n1 + n2 + nv);
+    for (int k = 0; k < 3; ++k) scn->leaf_host.insert(scn->leaf_host.end(), gr[k], gr[k] + n[k]);
+    scn->leaf_host.insert(scn->leaf_host.end(), values, values + nv);
+    for (int k = 0; k < 3; ++k) scn->leaf_n[k] = n[k];
+    scn->leaf_proj = proj_kind;
+    return OCD_OK;
 }
 
 int32_t ocd_scenario_create(const ocd_scenario_desc *desc, ocd_scenario **out)
@@ -166,7 +239,7 @@ int32_t ocd_scenario_create(const ocd_scenario_desc *desc, ocd_scenario **out)
     s->desc = *desc;
     s->K = desc->extra_inits ? 6 : 3;
     s->D = desc->n_lanes + 4;
-    for (int i = 0; i < OCD_MAX_DEVICES; ++i) s->dev_plans[i] = nullptr;
+    for (int i = 0; i < OCD_MAX_DEVICES; ++i) { s->dev_plans[i] = nullptr; s->dev_leaf[i] = nullptr; s->n_cus[i] = 0; }
     *out = s;
     return OCD_OK;
 }
@@ -176,6 +249,8 @@ void ocd_scenario_destroy(ocd_scenario *scn)
     if (!scn) return;
     for (int i = 0; i < OCD_MAX_DEVICES; ++i)
         if (scn->dev_plans[i]) (void)hipFree(scn->dev_plans[i]);
+    for (int i = 0; i < OCD_MAX_DEVICES; ++i)
+        if (scn->dev_leaf[i]) (void)hipFree(scn->dev_leaf[i]);
     delete scn;
 }
 
@@ -257,7 +332,7 @@ int32_t scripted_plans_device(const ocd_scenario *scn_c, hipStream_t st, const f
     float host[OCD_MAX_OTHERS * OCD_MAX_HORIZON * 2];
     for (int j = 0; j < NO; ++j)
         for (int t = 0; t < H; ++t) {
-            const float *src = (t < d.other_plan_len[j]) ? d.other_plan[j][t] : d.other_default[j];
+            const float *src = (t < d.other_plan_len[j]) ? d.other_plan[j][t] : d.other_assumed_default[j];
             host[(j * H + t) * 2] = src[0];
             host[(j * H + t) * 2 + 1] = src[1];
         }
@@ -328,6 +403,38 @@ int32_t ocd_rollout_from_state(const ocd_scenario *scn, const float *world_state
     p.t0 = first_step;
     p.sample_fixed = sample;
     return launch(scn, p, hip_stream);
+}
+
+int32_t ocd_mpc_reward_batch(const ocd_scenario *scn, const float *world_state,
+                             const float *weights, int32_t weights_per_problem,
+                             const float *controls, const float *other_plans,
+                             float *reward_out, float *grad_out, float *traj_out,
+                             int64_t B, void *hip_stream)
+{
+    if (!scn) return fail(OCD_ERR_INVALID_ARG, "scenario is NULL");
+    if (B < 0) return fail(OCD_ERR_INVALID_ARG, "B = %lld < 0", (long long)B);
+    if (B == 0) return OCD_OK;
+    if (!world_state || !controls) return fail(OCD_ERR_INVALID_ARG, "world_state / controls is NULL");
+    if (scn->desc.reward_kind == OCD_REWARD_LANE_FEATURES && !weights)
+        return fail(OCD_ERR_INVALID_ARG, "weights is NULL for a lane-feature reward");
+    int32_t st = need_device();
+    if (st != OCD_OK) return st;
+    ocd::KernelParams p;
+    base_params(scn, p);
+    st = device_state(scn, (hipStream_t)hip_stream, p);
+    if (st != OCD_OK) return st;
+    p.ego_states = world_state;
+    p.weights = weights;
+    p.weights_per_problem = weights_per_problem;
+    p.other_plans = other_plans;
+    p.n_problems = B;
+    bool supported = false;
+    const int L = scn->desc.reward_kind == OCD_REWARD_LANE_FEATURES ? scn->desc.n_lanes : 0;
+    hipError_t e = ocd::launch_objective(scn->desc.n_cars - 1, L, p, controls, reward_out, grad_out, traj_out,
+                                         (hipStream_t)hip_stream, &supported);
+    if (!supported) return fail(OCD_ERR_UNSUPPORTED, "objective kernel: %d scripted cars, %d lanes", scn->desc.n_cars - 1, L);
+    if (e != hipSuccess) return hip_fail(e, "objective_kernel launch");
+    return OCD_OK;
 }
 
 int32_t ocd_dynamics_batch(const float *states, const float *controls, float dt, float dt_sq, float friction,

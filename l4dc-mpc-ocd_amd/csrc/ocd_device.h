@@ -1,0 +1,538 @@
+// ocd_device.h -- device primitives shared by the planner kernels: the reference's math helpers, the
+// car dynamics step, the reward features with their reverse-mode adjoint, the terminal-value lookup.
+//
+// Reference (file:line relative to the reference tree):
+//   _f / smooth_threshold / smooth_bump       interact_drive/math_utils.py:7-31,59-97,135-180
+//   car_dynamics_step                         interact_drive/simulation_utils.py:9-21
+//   ThreeLaneTestCar.features                 experiments/merging.py:32-83
+//   LinearRewardCar.reward_fn                 interact_drive/car/linear_reward_car.py:49-55
+//   ValueFeature.interpolate_value            interact_drive/reward_design/value_interpolation.py:28-61
+//
+// Numerics: IEEE binary32, one rounding per TensorFlow op of the reference, -ffp-contract=off; the
+// operation order is the arithmetic contract of DESIGN.md section 3.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ocd.h"
+#include "ocd_devmath.h"
+
+namespace ocd {
+
+// ---------------------------------------------------------------- primitives
+__device__ __forceinline__ float min_tf(float a, float b) { return (a <= b) ? a : b; }
+__device__ __forceinline__ float max_tf(float a, float b) { return (a >= b) ? a : b; }
+
+// _f (math_utils.py:28-31)
+struct FTape { bool pos; float m, e, u; };
+
+__device__ __forceinline__ float f_fwd(float t, float shape, FTape &tp)
+{
+    const bool pos = t > 0.0f;
+    const float tc = pos ? t : (0.0f + 0.01f);
+    const float u = shape * tc;
+    const float m = -1.0f / u;
+    const float e = exp_le1(m);
+    tp.pos = pos; tp.m = m; tp.e = e; tp.u = u;
+    return pos ? e : 0.0f;
+}
+
+__device__ __forceinline__ float f_bwd(float g, float shape, const FTape &tp, float k /* (-m)/u */)
+{
+    const float g_e = tp.pos ? g : 0.0f;
+    const float g_m = g_e * tp.e;
+    const float g_u = g_m * k;
+    const float g_tc = g_u * shape;
+    return tp.pos ? g_tc : 0.0f;
+}
+
+// smooth_threshold (math_utils.py:87-95)
+struct ThrTape { FTape t1, t2; float den, S; };
+
+__device__ __forceinline__ float thr_fwd(float z, float lo, float width, float shape, ThrTape &tp)
+{
+    const float xd = z - lo;
+    const float F1 = f_fwd(xd, shape, tp.t1);
+    const float xd2 = width - xd;
+    const float F2 = f_fwd(xd2, shape, tp.t2);
+    const float den = F1 + F2;
+    const float S = F1 / den;
+    tp.den = den; tp.S = S;
+    return S;
+}
+
+__device__ __forceinline__ float thr_bwd(float g_S, float shape, const ThrTape &tp)
+{
+    const float g_F1a = g_S / tp.den;
+    const float g_den = g_S * ((-tp.S) / tp.den);
+    const float k1 = (-tp.t1.m) / tp.t1.u;      // shared by the two _f(x_diff) call sites
+    const float k2 = (-tp.t2.m) / tp.t2.u;
+    const float ga = f_bwd(g_F1a, shape, tp.t1, k1);
+    const float gb = f_bwd(g_den, shape, tp.t1, k1);
+    const float gc = f_bwd(g_den, shape, tp.t2, k2);
+    return (ga + gb) + (-gc);
+}
+
+// smooth_bump (math_utils.py:166-178); center/width precomputed per control step
+struct BumpTape { bool cond; float xc, q, m, e; };
+
+__device__ __forceinline__ float bump_fwd(float z, float center, float width, BumpTape &tp)
+{
+    const float zn = (z - center) / width;
+    const bool cond = (zn * zn) < 1.0f;
+    const float xc = cond ? zn : 0.0f;
+    const float q = 1.0f - xc * xc;
+    const float m = -1.0f / q;
+    const float arg = m + 1.0f;
+    const float e = exp_le1(arg);
+    tp.cond = cond; tp.xc = xc; tp.q = q; tp.m = m; tp.e = e;
+    return cond ? e : 0.0f;
+}
+
+__device__ __forceinline__ float bump_bwd(float g, float width, const BumpTape &tp)
+{
+    const float g_e = tp.cond ? g : 0.0f;
+    const float g_arg = g_e * tp.e;
+    const float g_q = g_arg * ((-tp.m) / tp.q);
+    const float g_xc2 = -g_q;
+    const float g_xc = (g_xc2 * 2.0f) * tp.xc;
+    const float g_zn = tp.cond ? g_xc : 0.0f;
+    return g_zn / width;
+}
+
+// car_dynamics_step (simulation_utils.py:9-21) on explicit cos/sin of the heading
+__device__ __forceinline__ void dyn_step(float x, float y, float v, float th, float c, float s,
+                                         float a, float w, float dt, float dt2, float f,
+                                         float &xn, float &yn, float &vn, float &thn)
+{
+    const float a_c = max_tf(min_tf(a, 4.0f), -8.0f);
+    const float w_c = max_tf(min_tf(w, 4.0f), -4.0f);
+    const float v2 = v * v;
+    const float fv2 = f * v2;
+    const float acc = a_c - fv2;
+    const float vdt = v * dt;
+    const float hA = 0.5f * acc;
+    const float hAdt2 = hA * dt2;
+    const float d = vdt + hAdt2;
+    xn = x + c * d;
+    yn = y + s * d;
+    vn = v + acc * dt;
+    thn = th + w_c * dt;
+}
+
+// bump centre / half-width of a scripted car at (ox, oy): smooth_bump(o - h, o + h)
+// (merging.py:72-73, math_utils.py:167-168)
+struct BumpGeom { float cx, wx, cy, wy; };
+
+__device__ __forceinline__ BumpGeom bump_geom(float ox, float oy, float hx, float hy)
+{
+    BumpGeom g;
+    const float sx = ox - hx, ex = ox + hx;
+    g.wx = (ex - sx) / 2.0f;
+    g.cx = (sx + ex) / 2.0f;
+    const float sy = oy - hy, ey = oy + hy;
+    g.wy = (ey - sy) / 2.0f;
+    g.cy = (sy + ey) / 2.0f;
+    return g;
+}
+
+struct Q4 { float qx, qy, qv, qth; };
+
+// 1.0f / (float)n for a tie count n in [1, 4]: the correctly rounded quotients as constants
+__device__ __forceinline__ float inv_count(int n)
+{
+    float r = 1.0f;
+    r = (n == 2) ? 0.5f : r;
+    r = (n == 3) ? (1.0f / 3.0f) : r;
+    r = (n == 4) ? 0.25f : r;
+    return r;
+}
+
+// Conservative per-lane tests for the wave-uniform feature skips.
+//  fence:  _f(x - lo) and _f(-x - lo) are both 0 (value AND gradient, math_utils.py:28-31) unless one
+//          argument is > 0, i.e. unless |x| > lo (a - b > 0 <=> a > b in IEEE arithmetic with gradual
+//          underflow); then S = 0/den = 0, the feature is 0*|x| and every adjoint term is +-0.
+//  collision: bump_x*bump_y and its gradients are +-0 unless x_norm^2 < 1 AND y_norm^2 < 1
+//          (math_utils.py:171-178); |z - c| < 1.001*w is a cheap superset of ((z-c)/w)^2 < 1.
+__device__ __forceinline__ bool needs_fence(const ocd_scenario_desc &d, float x)
+{
+    return __builtin_fabsf(x) > d.fence_lo;
+}
+
+__device__ __forceinline__ bool needs_collision1(float x, float y, const BumpGeom &g)
+{
+    const float dx = x - g.cx, dy = y - g.cy;
+    return (__builtin_fabsf(dx) < g.wx * 1.001f) && (__builtin_fabsf(dy) < g.wy * 1.001f);
+}
+
+// ---------------------------------------------------------------- reward, every feature evaluated
+// reward of one world state and (GRAD) its gradient w.r.t. the ego state
+// (merging.py:44-83, linear_reward_car.py:49-55, targetSpeedRewardMaximizerCar.py:50-56).
+// do_col / do_fence are WAVE-UNIFORM: false only when the caller has proved that, for every live lane,
+// the collision bumps / the fence thresholds are identically zero together with their gradients (see
+// needs_collision1 / needs_fence), so skipping them changes no bit of any result.
+template <int NO, int L, bool GRAD>
+__device__ __forceinline__ float reward_state(const ocd_scenario_desc &d, const float (&w)[OCD_MAX_FEATURES],
+                                              float x, float y, float v, float sn, float cn,
+                                              const BumpGeom (&bg)[NO > 0 ? NO : 1], Q4 &q,
+                                              float *feats /* nullptr or [D] global */,
+                                              const bool do_col = true, const bool do_fence = true)
+{
+    if (L == 0) {                                  // OCD_REWARD_TARGET_SPEED (the planner KAT car)
+        const float dv = v - d.target_speed;
+        const float sq = dv * dv;
+        if (GRAD) { q.qx = 0.0f; q.qy = 0.0f; q.qth = 0.0f; q.qv = (-1.0f * 2.0f) * dv; }
+        return 0.0f - sq;
+    }
+    constexpr int NOA = NO > 0 ? NO : 1;
+    const float tgt = d.target_speed;
+    const float bound = 4.0f * (tgt * tgt);
+    const float vel = v * sn;
+    const float dv = vel - tgt;
+    const float sq = dv * dv;
+    const bool pass0 = sq <= bound;
+    const float phi0 = min_tf(sq, bound);
+
+    constexpr int LA = L > 0 ? L : 1;
+    float rl[LA], pl[LA];
+    float pmin = 0.0f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const float diff = x - d.lane_center[l];
+        rl[l] = diff * -1.0f;
+        const float d2 = rl[l] * rl[l];
+        pl[l] = d2 * 10.0f;
+        pmin = (l == 0) ? pl[0] : min_tf(pmin, pl[l]);
+    }
+    int ntie_min = 0;
+#pragma unroll
+    for (int l = 0; l < L; ++l) ntie_min += (pl[l] == pmin) ? 1 : 0;
+
+    BumpTape bx[NOA], by[NOA];
+    float bxv[NOA], byv[NOA], col[NOA];
+    float pcol = 0.0f;
+    int ntie_col = NO;
+    ThrTape tp_f;
+    const bool side_p = x > d.fence_lo;
+    float Ssum = 0.0f, ax = 0.0f, pf = 0.0f;
+    if (do_col) {
+#pragma unroll
+        for (int j = 0; j < NO; ++j) {
+            bxv[j] = bump_fwd(x, bg[j].cx, bg[j].wx, bx[j]);
+            byv[j] = bump_fwd(y, bg[j].cy, bg[j].wy, by[j]);
+            col[j] = bxv[j] * byv[j];
+            pcol = (j == 0) ? col[0] : max_tf(pcol, col[j]);
+        }
+        ntie_col = 0;
+#pragma unroll
+        for (int j = 0; j < NO; ++j) ntie_col += (col[j] == pcol) ? 1 : 0;
+    }
+    // fences = (S(x) + S(-x)) * |x| (merging.py:80-81).  With threshold - width = fence_lo >= 0 the two
+    // arguments x - lo and -x - lo cannot both be positive, and a side whose argument is <= 0 has
+    // F1 = 0 exactly: S = 0/den = 0 and every adjoint term of that side is +-0 (see needs_fence).  So
+    // one smooth_threshold evaluation on the possibly-active side gives S(x) + S(-x) and its gradient
+    // bit for bit (x + 0 = x), at half the divisions and exponentials.
+    if (do_fence) {
+        Ssum = thr_fwd(side_p ? x : -x, d.fence_lo, d.fence_width, d.fence_shape, tp_f);
+        ax = (x < 0.0f) ? -x : x;
+        pf = Ssum * ax;
+    }
+
+    // reduce_sum(weights * feats), left to right over [phi0, lanes..., min, collision, fences]
+    float r = w[0] * phi0;
+#pragma unroll
+    for (int l = 0; l < L; ++l) r = r + w[1 + l] * pl[l];
+    const float w_min = w[L + 1], w_col = w[L + 2], w_f = w[L + 3];
+    r = r + w_min * pmin;
+    if (do_col) r = r + w_col * pcol;              // skipped terms are exactly +-0
+    if (do_fence) r = r + w_f * pf;
+    if (feats) {
+        feats[0] = phi0;
+#pragma unroll
+        for (int l = 0; l < L; ++l) feats[1 + l] = pl[l];
+        feats[L + 1] = pmin; feats[L + 2] = pcol; feats[L + 3] = pf;
+    }
+    if (!GRAD) return r;
+
+    const float g_sq = pass0 ? w[0] : 0.0f;
+    const float g_dv = (g_sq * 2.0f) * dv;
+    q.qv = g_dv * sn;
+    const float g_sn = g_dv * v;
+    q.qth = g_sn * cn;
+
+    float qx = 0.0f, qy = 0.0f;
+    const float min_share = inv_count(ntie_min) * w_min;          // (indicator / num_ties) * grad
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        float g = w[1 + l];
+        g = (pl[l] == pmin) ? (g + min_share) : g;
+        const float g_d2 = g * 10.0f;
+        const float g_r = (g_d2 * 2.0f) * rl[l];
+        qx = qx + g_r * -1.0f;
+    }
+    if (NO > 0 && do_col) {
+        const float col_share = inv_count(ntie_col) * w_col;
+#pragma unroll
+        for (int j = 0; j < NO; ++j) {
+            const float share = (col[j] == pcol) ? col_share : 0.0f;
+            const float g_bx = share * byv[j];
+            const float g_by = share * bxv[j];
+            qx = qx + bump_bwd(g_bx, bg[j].wx, bx[j]);
+            qy = qy + bump_bwd(g_by, bg[j].wy, by[j]);
+        }
+    }
+    if (do_fence) {
+        const float g_Ssum = w_f * ax;
+        const float g_ax = w_f * Ssum;
+        const float g_z = thr_bwd(g_Ssum, d.fence_shape, tp_f);
+        qx = qx + (side_p ? g_z : -g_z);
+        const float sgn = (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f);
+        qx = qx + g_ax * sgn;
+    }
+    q.qx = qx; q.qy = qy;
+    return r;
+}
+
+// ---------------------------------------------------------------- reward, one active feature per lane
+// Precondition (WAVE-UNIFORM, proved by the caller with needs_fence / needs_collision1): every live lane
+// has AT MOST ONE active feature among {fence, collision with scripted car 0, ..., car NO-1}; `is_f`
+// marks the lanes whose active feature is the fence, nc[j] the lanes inside car j's bump box.
+//
+// The fence is built from two "exp(-1/u + c)" units -- _f(x_diff) and _f(width - x_diff), c = 0 -- and so
+// is a collision term -- the x bump and the y bump, c = 1.  Each lane feeds the two units of ITS feature
+// through one shared instruction stream; the features it does not evaluate are exactly 0 with +-0
+// adjoints (see needs_fence / needs_collision1), so the result is the full evaluation's bit for bit:
+// same operations on the same values (m + 0.0f == m), sums that only skip +-0 terms.  Likewise the two
+// divisions of a lane's backward pass (g/den and (-S)/den of the fence, g_zn/width of the two bumps)
+// share two division slots.
+//   collision ties (reduce_max over cars, merging.py:78): the cars a lane does not evaluate have
+//   col == 0 exactly, so the evaluated car is the maximum, tied with all others iff its own col is 0.
+// has_col / has_f (wave-uniform): some live lane is a collision / fence lane.
+template <int NO, int L, bool GRAD>
+__device__ __forceinline__ float reward_one(const ocd_scenario_desc &d, const float (&w)[OCD_MAX_FEATURES],
+                                            float x, float y, float v, float sn, float cn,
+                                            const BumpGeom (&bg)[NO > 0 ? NO : 1], const bool (&nc)[NO > 0 ? NO : 1],
+                                            const bool is_f, const bool has_col, const bool has_f, Q4 &q)
+{
+    static_assert(L > 0 && NO > 0, "lane-feature reward only");
+    const float tgt = d.target_speed;
+    const float bound = 4.0f * (tgt * tgt);
+    const float vel = v * sn;
+    const float dv = vel - tgt;
+    const float sq = dv * dv;
+    const bool pass0 = sq <= bound;
+    const float phi0 = min_tf(sq, bound);
+
+    float rl[L], pl[L];
+    float pmin = 0.0f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const float diff = x - d.lane_center[l];
+        rl[l] = diff * -1.0f;
+        const float d2 = rl[l] * rl[l];
+        pl[l] = d2 * 10.0f;
+        pmin = (l == 0) ? pl[0] : min_tf(pmin, pl[l]);
+    }
+
+    // the one scripted car this lane may be colliding with
+    BumpGeom g = bg[0];
+#pragma unroll
+    for (int j = 1; j < NO; ++j) {
+        g.cx = nc[j] ? bg[j].cx : g.cx; g.wx = nc[j] ? bg[j].wx : g.wx;
+        g.cy = nc[j] ? bg[j].cy : g.cy; g.wy = nc[j] ? bg[j].wy : g.wy;
+    }
+    // inputs of the fence units
+    const bool side_p = x > d.fence_lo;
+    const float z = side_p ? x : -x;
+    const float xd = z - d.fence_lo;
+    const bool pos1 = xd > 0.0f;
+    const float uf1 = d.fence_shape * (pos1 ? xd : (0.0f + 0.01f));
+    const float xd2 = d.fence_width - xd;
+    const bool pos2 = xd2 > 0.0f;
+    const float uf2 = d.fence_shape * (pos2 ? xd2 : (0.0f + 0.01f));
+    // inputs of the bump units
+    bool condx = false, condy = false;
+    float xcx = 0.0f, xcy = 0.0f;
+    if (has_col) {
+        const float znx = (x - g.cx) / g.wx;
+        condx = (znx * znx) < 1.0f;
+        xcx = condx ? znx : 0.0f;
+        const float zny = (y - g.cy) / g.wy;
+        condy = (zny * zny) < 1.0f;
+        xcy = condy ? zny : 0.0f;
+    }
+    // the two shared units
+    const float u1 = is_f ? uf1 : (1.0f - xcx * xcx);
+    const float u2 = is_f ? uf2 : (1.0f - xcy * xcy);
+    const float addc = is_f ? 0.0f : 1.0f;
+    const float m1 = -1.0f / u1, m2 = -1.0f / u2;
+    const float e1 = exp_le1(m1 + addc), e2 = exp_le1(m2 + addc);
+    // fence outputs (meaningful on fence lanes)
+    float den = 1.0f, S = 0.0f, Ssum = 0.0f, ax = 0.0f, pf = 0.0f;
+    if (has_f) {
+        const float F1 = pos1 ? e1 : 0.0f, F2 = pos2 ? e2 : 0.0f;
+        den = F1 + F2;
+        S = F1 / den;
+        ax = (x < 0.0f) ? -x : x;
+        Ssum = is_f ? S : 0.0f;
+        pf = is_f ? (S * ax) : 0.0f;
+    }
+    // bump outputs (meaningful on the other lanes)
+    const float bxv = condx ? e1 : 0.0f;
+    const float byv = condy ? e2 : 0.0f;
+    const float pcol = is_f ? 0.0f : (bxv * byv);
+
+    const float w_min = w[L + 1], w_col = w[L + 2], w_f = w[L + 3];
+    if (!GRAD) {
+        float r = w[0] * phi0;
+#pragma unroll
+        for (int l = 0; l < L; ++l) r = r + w[1 + l] * pl[l];
+        r = r + w_min * pmin;
+        r = r + w_col * pcol;                      // a skipped feature's term is exactly +-0
+        r = r + w_f * pf;
+        return r;
+    }
+
+    const float k1 = (-m1) / u1, k2 = (-m2) / u2;
+    const float g_sq = pass0 ? w[0] : 0.0f;
+    const float g_dv = (g_sq * 2.0f) * dv;
+    q.qv = g_dv * sn;
+    const float g_sn = g_dv * v;
+    q.qth = g_sn * cn;
+
+    int ntie_min = 0;
+#pragma unroll
+    for (int l = 0; l < L; ++l) ntie_min += (pl[l] == pmin) ? 1 : 0;
+    float qx = 0.0f;
+    const float min_share = inv_count(ntie_min) * w_min;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        float gl = w[1 + l];
+        gl = (pl[l] == pmin) ? (gl + min_share) : gl;
+        const float g_d2 = gl * 10.0f;
+        const float g_r = (g_d2 * 2.0f) * rl[l];
+        qx = qx + g_r * -1.0f;
+    }
+    // collision adjoint up to the division by the bump width (zero on fence lanes)
+    const float col_share = ((NO == 1) ? 1.0f : ((pcol == 0.0f) ? inv_count(NO) : 1.0f)) * w_col;
+    const float g_bx = is_f ? 0.0f : (col_share * byv);
+    const float g_by = is_f ? 0.0f : (col_share * bxv);
+    const float gx_e = condx ? g_bx : 0.0f;
+    const float gx_q = (gx_e * e1) * k1;
+    const float gx_xc = ((-gx_q) * 2.0f) * xcx;
+    const float g_znx = condx ? gx_xc : 0.0f;
+    const float gy_e = condy ? g_by : 0.0f;
+    const float gy_q = (gy_e * e2) * k2;
+    const float gy_xc = ((-gy_q) * 2.0f) * xcy;
+    const float g_zny = condy ? gy_xc : 0.0f;
+    // fence adjoint up to its two divisions by den
+    const float g_Ssum = w_f * ax;
+    const float g_ax = w_f * Ssum;
+    // the two shared division slots
+    const float q1 = (is_f ? g_Ssum : g_znx) / (is_f ? den : g.wx);   // g_S/den           | g_zn_x / width_x
+    const float q2 = (is_f ? -S : g_zny) / (is_f ? den : g.wy);       // (-S)/den          | g_zn_y / width_y
+    float qx_f = qx;
+    if (has_f) {
+        const float g_den = g_Ssum * q2;
+        FTape t1, t2;
+        t1.pos = pos1; t1.m = m1; t1.e = e1; t1.u = u1;
+        t2.pos = pos2; t2.m = m2; t2.e = e2; t2.u = u2;
+        const float ga = f_bwd(q1, d.fence_shape, t1, k1);
+        const float gb = f_bwd(g_den, d.fence_shape, t1, k1);
+        const float gc = f_bwd(g_den, d.fence_shape, t2, k2);
+        const float g_z = (ga + gb) + (-gc);
+        const float sgn = (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f);
+        qx_f = (qx + (side_p ? g_z : -g_z)) + g_ax * sgn;
+    }
+    q.qx = is_f ? qx_f : (qx + q1);
+    q.qy = is_f ? 0.0f : (0.0f + q2);
+    return 0.0f;
+}
+
+// ---------------------------------------------------------------- terminal value (leaf_evaluation)
+// ValueFeature.interpolate_value (value_interpolation.py:28-61): trilinear interpolation of a value
+// table over the coarse state proj(world_state) = (x, y, v) or (x, y, v*sin(heading)); NaN outside the
+// grid.  Layout and semantics: include/ocd.h, ocd_scenario_set_leaf_value.
+struct LeafTable {
+    const float *grid;        // [n0 + n1 + n2] cell boundaries, ascending per dimension
+    const float *values;      // [n0, n1, n2]
+    int32_t n[3];
+    int32_t proj_kind;        // 0: (x, y, v)   1: (x, y, v * sin(heading))
+};
+
+// last index i in [0, n-2] with grid[i] <= x (x is inside [grid[0], grid[n-1]])
+__device__ __forceinline__ int leaf_corner(const float *gr, int n, float x)
+{
+    // start from the uniform-grid guess, then walk: exact for any ascending grid
+    const float span = gr[n - 1] - gr[0];
+    int c = (span > 0.0f) ? (int)(((x - gr[0]) / span) * (float)(n - 1)) : 0;
+    c = c < 0 ? 0 : (c > n - 2 ? n - 2 : c);
+    while (c < n - 2 && gr[c + 1] <= x) ++c;
+    while (c > 0 && gr[c] > x) --c;
+    return c;
+}
+
+// value and (GRAD) gradient w.r.t. the ego state of the terminal value at (x, y, v, heading)
+template <bool GRAD>
+__device__ __forceinline__ float leaf_value(const LeafTable &lt, float x, float y, float v, float sn, float cn, Q4 &q)
+{
+    const float xc[3] = {x, y, (lt.proj_kind == 1) ? (v * sn) : v};
+    const float *gr[3] = {lt.grid, lt.grid + lt.n[0], lt.grid + lt.n[0] + lt.n[1]};
+    bool inside = true;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) inside = inside && (xc[k] >= gr[k][0]) && (xc[k] <= gr[k][lt.n[k] - 1]);
+    const float nanv = __int_as_float(0x7fc00000);
+    if (GRAD) { q.qx = nanv; q.qy = nanv; q.qv = nanv; q.qth = nanv; }
+    if (!inside) return nanv;
+    int c[3];
+    float a[3], st[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        c[k] = leaf_corner(gr[k], lt.n[k], xc[k]);
+        st[k] = gr[k][c[k] + 1] - gr[k][c[k]];
+        a[k] = xc[k] - gr[k][c[k]];
+    }
+    const float cell = (st[0] * st[1]) * st[2];
+    // p[k][i]: (-1)**(i+1) * (x - g) + (1 - i) * step
+    float p[3][2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        p[k][0] = (-1.0f * a[k]) + (1.0f * st[k]);
+        p[k][1] = (1.0f * a[k]) + (0.0f * st[k]);
+    }
+    float sum = 0.0f;
+    float ga[3] = {0.0f, 0.0f, 0.0f};               // d sum / d a[k]
+#pragma unroll
+    for (int i0 = 0; i0 < 2; ++i0)
+#pragma unroll
+        for (int i1 = 0; i1 < 2; ++i1)
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2) {
+                const float val = lt.values[((size_t)(c[0] + i0) * lt.n[1] + (c[1] + i1)) * lt.n[2] + (c[2] + i2)];
+                const float pv01 = p[0][i0] * p[1][i1];
+                const float pv = pv01 * p[2][i2];
+                const float num = val * pv;
+                sum = sum + num / cell;
+                if (GRAD) {
+                    // term = (val * pv) / cell ; pv = (p0 * p1) * p2
+                    const float g_num = 1.0f / cell;
+                    const float g_pv = g_num * val;
+                    const float g_p2 = g_pv * pv01;
+                    const float g_pv01 = g_pv * p[2][i2];
+                    const float g_p0 = g_pv01 * p[1][i1];
+                    const float g_p1 = g_pv01 * p[0][i0];
+                    ga[0] = ga[0] + g_p0 * (i0 ? 1.0f : -1.0f);
+                    ga[1] = ga[1] + g_p1 * (i1 ? 1.0f : -1.0f);
+                    ga[2] = ga[2] + g_p2 * (i2 ? 1.0f : -1.0f);
+                }
+            }
+    if (GRAD) {
+        q.qx = ga[0];
+        q.qy = ga[1];
+        if (lt.proj_kind == 1) { q.qv = ga[2] * sn; q.qth = (ga[2] * v) * cn; }
+        else { q.qv = ga[2]; q.qth = 0.0f; }
+    }
+    return sum;
+}
+
+} // namespace ocd

@@ -9,6 +9,23 @@ namespace ocd {
 
 enum { OCD_MODE_ROLLOUT = 0, OCD_MODE_PLAN = 1 };
 
+// How the lanes of a wavefront exchange the terms of the horizon recurrences
+enum {
+    V_LDS = 0,   // K wavefronts per workgroup (one per control initialisation), segments of H lanes,
+                 // zero-padded LDS windows: any H, the throughput variant
+    V_ROW = 1,   // K wavefronts per workgroup, one trajectory per 16-lane DPP row (H <= 16): row_shr/row_shl
+    V_SEG = 2    // ONE wavefront per workgroup holding all K initialisations of its trajectories in
+                 // segments of H lanes (K*H <= 64): wave_shr/wave_shl moves, argmin inside the wavefront
+};
+
+// Terminal-value table of the planner (leaf_evaluation); device pointers owned by the scenario handle
+struct LeafParams {
+    const float *grid;        // [n0 + n1 + n2]
+    const float *values;      // [n0, n1, n2]
+    int32_t n[3];
+    int32_t proj_kind;
+};
+
 // Kernel argument block (passed by value: lives in the kernarg segment, read
 // through scalar loads, so scenario constants cost no vector registers).
 struct KernelParams {
@@ -24,39 +41,49 @@ struct KernelParams {
     int32_t *best_init_out;    // PLAN [B] or nullptr
     float *all_plans_out;      // PLAN [B,K,H,2] or nullptr
     float *all_losses_out;     // PLAN [B,K] or nullptr
+    LeafParams leaf;           // leaf.values == nullptr: no terminal value
     long long n_problems;      // trajectories handled by this launch
     long long ep_begin;        // ROLLOUT: flat index of the first episode
     long long N;               // ROLLOUT: number of init states
     int32_t S;                 // ROLLOUT: samples per (candidate, init)
     int32_t mode;
     int32_t weights_per_problem;
-    int32_t K;                 // control initialisations = wavefronts per workgroup
+    int32_t K;                 // control initialisations
     int32_t T;                 // control steps to run (ROLLOUT); 1 in PLAN mode
     int32_t t0;                // world step index of the first control step (scripted plans, teleport)
     int32_t from_state;        // ROLLOUT: 1 = every problem starts from its own world_state [B,C,4]
     int32_t sample_fixed;      // from_state: which world.reset() outcome (teleported car) applies
-    int32_t segs_used;         // trajectories per wavefront (<= 64/H); 0 = let the launcher choose
+    int32_t reset_phase;       // ROLLOUT: world.reset() calls before episode 0 of this batch (teleport cycle)
+    int32_t segs_used;         // trajectories per wavefront; 0 = let the launcher choose
     int32_t no_skips;          // diagnostics: 1 = always evaluate collision and fence features
-    int32_t scan_mode;         // 0 = automatic, 1 = LDS-window recurrences, 2 = DPP-row recurrences (H <= 16)
-    int32_t no_unify;          // diagnostics: 1 = never share the exp(-1/u) units between fence and collision
+    int32_t scan_mode;         // 0 = automatic, 1 = V_LDS, 2 = V_ROW, 3 = V_SEG
+    int32_t no_unify;          // diagnostics: 1 = never use the one-feature-per-lane evaluation
+    int32_t n_cus;             // compute units of the device (launch shape heuristics)
 };
 
-// (horizon H, scripted cars NO, lanes L) triples with a compiled planner kernel; L = 0 is the
-// target-speed test reward (no lane features).  Horizons 5/6: the reference's own settings;
-// 10/15/25: BASELINE.json configs 2-5; the rest for tests and sweeps.  Anything else returns
-// OCD_ERR_UNSUPPORTED.
+// (horizon H, scripted cars NO, lanes L) triples with a planner kernel specialised on H (loops fully
+// unrolled, all three exchange variants).  Horizons 5/6: the reference's own settings; 10/15/25:
+// BASELINE.json configs 2-5; 3: the reference's planner known-answer test.  Every other horizon in
+// [1, OCD_MAX_HORIZON] runs the generic kernel of its (NO, L) pair (run-time H, V_LDS).
 #define OCD_KERNEL_TABLE(X)                                                                   \
     X(3, 0, 0) X(5, 0, 0)                                                                     \
-    X(3, 1, 3) X(4, 1, 3) X(5, 1, 3) X(6, 1, 3) X(8, 1, 3) X(10, 1, 3) X(12, 1, 3)            \
-    X(15, 1, 3) X(16, 1, 3) X(20, 1, 3) X(25, 1, 3) X(32, 1, 3)                               \
-    X(5, 2, 2) X(6, 2, 2) X(10, 2, 2) X(15, 2, 2) X(20, 2, 2)                                 \
-    X(3, 2, 3) X(5, 2, 3) X(8, 2, 3) X(10, 2, 3) X(25, 2, 3) X(5, 3, 3)
+    X(5, 1, 3) X(6, 1, 3) X(10, 1, 3) X(15, 1, 3) X(25, 1, 3)                                 \
+    X(5, 2, 2) X(10, 2, 2) X(15, 2, 2)                                                        \
+    X(5, 2, 3) X(10, 2, 3) X(25, 2, 3)
 
-// (scripted cars, lanes) pairs of the reward-only kernel
-#define OCD_REWARD_TABLE(X) X(0, 0) X(1, 2) X(1, 3) X(2, 2) X(2, 3) X(3, 2) X(3, 3) X(1, 1) X(2, 1) X(1, 4) X(2, 4)
+// (scripted cars NO, lanes L) pairs: generic planner kernel, reward kernel, objective kernel.
+// L = 0 is the target-speed test reward (any number of cars: the others do not enter it).
+#define OCD_PAIR_TABLE(X)                                                                     \
+    X(0, 0) X(1, 0) X(2, 0) X(3, 0)                                                           \
+    X(1, 1) X(1, 2) X(1, 3) X(1, 4)                                                           \
+    X(2, 1) X(2, 2) X(2, 3) X(2, 4)                                                           \
+    X(3, 1) X(3, 2) X(3, 3) X(3, 4)
 
 hipError_t launch_mpc_dispatch(int H, int NO, int L, const KernelParams &p, hipStream_t st, bool *supported);
 hipError_t launch_reward(int NO, int L, const KernelParams &p, float *feats, float *rew, hipStream_t st, bool *supported);
+// R(u) and dR/du for caller-supplied controls [B,H,2] (naive_planner.py:33-77)
+hipError_t launch_objective(int NO, int L, const KernelParams &p, const float *controls, float *reward_out,
+                            float *grad_out, float *traj_out, hipStream_t st, bool *supported);
 hipError_t launch_math(const float *in, float *e, float *s, float *c, long long n, hipStream_t st);
 hipError_t launch_dynamics(const float *states, const float *controls, float dt, float dt_sq, float friction,
                            float *out, long long n, hipStream_t st);

@@ -96,6 +96,24 @@ class Engine(DeviceOps):
             self.lib.ocd_scenario_destroy(h)
             self._h = None
 
+    def set_option(self, name: str, value: int) -> None:
+        """Per-handle tuning / bookkeeping option (include/ocd.h: ocd_scenario_set_option)."""
+        abi.check(self.lib, self.lib.ocd_scenario_set_option(self._h, name.encode(), int(value)))
+
+    def set_leaf_value(self, disc_grid, values, proj_kind: int = 0) -> None:
+        """Terminal value of the planner: ValueFeature(disc_grid, v_grids[t]) as leaf_evaluation
+        (value_interpolation.py:28-61, naive_planner.py:69-70).  values=None removes it."""
+        if values is None:
+            abi.check(self.lib, self.lib.ocd_scenario_set_leaf_value(self._h, None, 0, None, 0, None, 0, None, 0))
+            return
+        g = [np.ascontiguousarray(np.asarray(a, dtype=np.float32)) for a in disc_grid]
+        v = np.ascontiguousarray(np.asarray(values, dtype=np.float32))
+        if len(g) != 3 or v.shape != tuple(len(a) for a in g):
+            raise ValueError("disc_grid must hold 3 axes and values must have shape (n0, n1, n2)")
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        abi.check(self.lib, self.lib.ocd_scenario_set_leaf_value(
+            self._h, fp(g[0]), len(g[0]), fp(g[1]), len(g[1]), fp(g[2]), len(g[2]), fp(v), int(proj_kind)))
+
     # ------------------------------------------------------------------ entry points
     def plan_batch(self, world_state, weights=None, other_plans="scenario", want_all: bool = False,
                    to_numpy: bool = True) -> Dict[str, object]:
@@ -188,6 +206,38 @@ class Engine(DeviceOps):
         self._call(self.lib.ocd_time_rollout, self._h, _ptr(init_dev), _ptr(w_dev), P, N, ep_begin, ep_end,
                    _ptr(ret_dev), reps, C.byref(ms), self._stream())
         return float(ms.value)
+
+    def mpc_reward_batch(self, world_state, weights, controls, other_plans="scenario", want_grad: bool = True,
+                         want_traj: bool = False) -> Dict[str, np.ndarray]:
+        """NaivePlanner.reward_func and its gradient for caller-supplied controls [B, H, 2]
+        (naive_planner.py:33-77)."""
+        d = self.desc
+        ws = self._to_dev(world_state).reshape(-1, d.n_cars, 4)
+        B = ws.shape[0]
+        H = d.horizon
+        u = self._to_dev(controls).reshape(-1, H, 2)
+        if u.shape[0] == 1 and B > 1:
+            u = u.expand(B, H, 2).contiguous()
+        if u.shape[0] != B:
+            raise ValueError(f"controls has {u.shape[0]} rows for {B} world states")
+        w = None if weights is None else self._to_dev(weights)
+        per = int(w is not None and w.dim() == 2)
+        if isinstance(other_plans, str):
+            op = self._other_plans
+        else:
+            op = None if other_plans is None else self._to_dev(other_plans).reshape(d.n_cars - 1, H, 2)
+        rew = torch.empty((B,), dtype=torch.float32, device=self.device)
+        grad = torch.empty((B, H, 2), dtype=torch.float32, device=self.device) if want_grad else None
+        traj = torch.empty((B, H, 4), dtype=torch.float32, device=self.device) if want_traj else None
+        self._call(self.lib.ocd_mpc_reward_batch, self._h, _ptr(ws), _ptr(w), per, _ptr(u), _ptr(op), _ptr(rew),
+                   _ptr(grad), _ptr(traj), B, self._stream())
+        torch.cuda.synchronize(self.device)
+        out = dict(reward=rew.cpu().numpy())
+        if want_grad:
+            out["grad"] = grad.cpu().numpy()
+        if want_traj:
+            out["traj"] = traj.cpu().numpy()
+        return out
 
     def reward_batch(self, world_state, weights):
         d = self.desc

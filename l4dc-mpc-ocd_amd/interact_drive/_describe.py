@@ -38,6 +38,7 @@ def describe(world, car, horizon: int, learning_rate: float = 0.1, n_iter: int =
     d.episode_len = int(episode_len)
     d.n_samples = int(n_samples)
     d.teleport_step = int(getattr(world, "_teleport_step", 0))
+    d.teleport_period = int(getattr(world, "_teleport_period", 0))
     tc = world._teleport_cars() if hasattr(world, "_teleport_cars") else [-1] * abi.OCD_MAX_SAMPLES
     for s in range(abi.OCD_MAX_SAMPLES):
         d.teleport_car[s] = tc[s]
@@ -79,9 +80,16 @@ def describe(world, car, horizon: int, learning_rate: float = 0.1, n_iter: int =
             d.other_plan_len[j] = len(other.plan)
             for t, u in enumerate(other.plan):
                 d.other_plan[j][t][0], d.other_plan[j][t][1] = float(u[0]), float(u[1])
+            if other.default_control is None and episode_len > len(other.plan):
+                # the reference's FixedPlanCar.step sets control = None past the plan and then fails
+                raise NotImplementedError("FixedPlanCar without default_control stepped beyond its plan")
             dc = other.default_control if other.default_control is not None else other.plan[-1]
             d.other_default[j][0], d.other_default[j][1] = float(dc[0]), float(dc[1])
+            # what a check_plans planner assumes beyond the plan (planner_car.py:66-75)
+            if other.default_control is not None:
+                d.other_assumed_default[j][0], d.other_assumed_default[j][1] = float(dc[0]), float(dc[1])
         elif isinstance(other, FixedControlCar):
+            # no .plan attribute: a check_plans planner assumes (0, 0) for it (planner_car.py:76-77)
             d.other_plan_len[j] = 0
             d.other_default[j][0], d.other_default[j][1] = float(other.control[0]), float(other.control[1])
         else:

@@ -34,6 +34,8 @@ class ReplanningCarWorld(TwoLaneCarWorld):
     def _teleport_step(self):
         return self.critical_t
 
+    _teleport_period = 2          # reset() toggles on every call, whatever the init or sample
+
     def _teleport_cars(self):
         first = 3 - self.unlucky_car_idx
         return [first, 3 - first, first, 3 - first]

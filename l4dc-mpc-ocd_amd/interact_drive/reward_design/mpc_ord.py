@@ -65,9 +65,8 @@ class MPC_ORD:
         else:
             ret = eng.rollout(init, w32)["returns"]
         # keep world.reset() side effects in step with the reference (ReplanningCarWorld toggles per reset)
-        for _ in range(N * S):
-            if hasattr(self.world, "unlucky_car_idx"):
-                self.world.unlucky_car_idx = 2 if self.world.unlucky_car_idx == 1 else 1
+        if hasattr(self.world, "unlucky_car_idx") and (P * N * S) % 2:
+            self.world.unlucky_car_idx = 2 if self.world.unlucky_car_idx == 1 else 1
         return ret.reshape(P, N, S)
 
     # ------------------------------------------------------------------ reference API

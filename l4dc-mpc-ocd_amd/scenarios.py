@@ -114,7 +114,7 @@ class Scenario:
         out = np.zeros((no, H, 2), dtype=np.float32)
         for j in range(no):
             for t in range(H):
-                src = d.other_plan[j][t] if t < d.other_plan_len[j] else d.other_default[j]
+                src = d.other_plan[j][t] if t < d.other_plan_len[j] else d.other_assumed_default[j]
                 out[j, t, 0], out[j, t, 1] = src[0], src[1]
         return out
 
@@ -139,6 +139,7 @@ def _base_desc(horizon: int, n_iter: int, extra_inits: bool, episode_len: int) -
     d.episode_len = episode_len
     d.n_samples = 1
     d.teleport_step = 0
+    d.teleport_period = 0
     for s in range(abi.OCD_MAX_SAMPLES):
         d.teleport_car[s] = -1
     for k, v in enumerate((10., 0., 0., 0.)):      # replanning_world.py:34 (unused unless teleport_step > 0)
@@ -165,7 +166,10 @@ def _set_lanes(d: abi.ScenarioDesc, centers: Sequence[float]) -> None:
 
 
 def _set_other(d: abi.ScenarioDesc, j: int, init, friction: float,
-               plan: Sequence[Sequence[float]] = (), default=(0.0, 0.0)) -> None:
+               plan: Sequence[Sequence[float]] = (), default=(0.0, 0.0), assumed_default=None) -> None:
+    """assumed_default: what a check_plans planner assumes beyond the plan (planner_car.py:66-75):
+    the car's default_control if it has a plan and one, else (0, 0); defaults to `default` for a
+    FixedPlanCar (plan given) and to (0, 0) otherwise."""
     for k in range(4):
         d.other_init[j][k] = np.float32(init[k])
     d.other_friction[j] = friction
@@ -173,6 +177,9 @@ def _set_other(d: abi.ScenarioDesc, j: int, init, friction: float,
     for t, u in enumerate(plan):
         d.other_plan[j][t][0], d.other_plan[j][t][1] = u[0], u[1]
     d.other_default[j][0], d.other_default[j][1] = default[0], default[1]
+    if assumed_default is None:
+        assumed_default = default if len(plan) else (0.0, 0.0)
+    d.other_assumed_default[j][0], d.other_assumed_default[j][1] = assumed_default[0], assumed_default[1]
 
 
 def _set_designer(d: abi.ScenarioDesc, w32: np.ndarray) -> None:
@@ -234,7 +241,10 @@ def replanning(horizon: int = 5, n_iter: int = 100) -> Scenario:
     _set_other(d, 1, (0., -0.7, 0.8, _PI_2), friction=0.2, plan=plan2)
     # critical_t = 4; reset() toggles unlucky_car_idx 1 <-> 2 and setup_world() resets once, so the
     # first sample of every init removes car 1 and the second removes car 2 (replanning_world.py:18-36,93)
+    # The toggle happens on EVERY reset, whatever the init or sample: a cycle of period 2 over the flat
+    # episode index (with the reference's num_samples = 2 that is the sample index).
     d.teleport_step = 4
+    d.teleport_period = 2
     for s in range(abi.OCD_MAX_SAMPLES):
         d.teleport_car[s] = 1 + (s % 2)
     raw = np.array([-3, 0, 0, -2, -10, -10], dtype=np.float32)

@@ -288,6 +288,80 @@ static float reward_state(const ocd_scenario_desc *d, const float *w,
     return r;
 }
 
+/* ---- terminal value: ValueFeature.interpolate_value (value_interpolation.py:28-61) ----
+ * Trilinear interpolation of a value table over the coarse state proj(world_state); NaN outside the
+ * grid.  The reference never calls it (no scenario sets leaf_evaluation) and holds no vector for it:
+ * PARITY UNPINNED; the op order below (one rounding per TensorFlow op, sum over the 8 corners in
+ * itertools.product order, gradient accumulated in that same order) is the contract the HIP kernel shares. */
+static struct {
+    const float *grid[3];
+    const float *values;
+    int n[3];
+    int proj_kind;
+} g_leaf = {{0, 0, 0}, 0, {0, 0, 0}, 0};
+
+void ocd_oracle_set_leaf_value(const float *grid0, int32_t n0, const float *grid1, int32_t n1,
+                               const float *grid2, int32_t n2, const float *values, int32_t proj_kind)
+{
+    g_leaf.grid[0] = grid0; g_leaf.grid[1] = grid1; g_leaf.grid[2] = grid2;
+    g_leaf.n[0] = n0; g_leaf.n[1] = n1; g_leaf.n[2] = n2;
+    g_leaf.values = values;
+    g_leaf.proj_kind = proj_kind;
+}
+
+static float leaf_value(float x, float y, float v, float sn, float cn, q4 *q)
+{
+    const float xc[3] = {x, y, (g_leaf.proj_kind == 1) ? (v * sn) : v};
+    const float nanv = 0.0f / 0.0f;
+    int inside = 1;
+    for (int k = 0; k < 3; ++k)
+        inside = inside && (xc[k] >= g_leaf.grid[k][0]) && (xc[k] <= g_leaf.grid[k][g_leaf.n[k] - 1]);
+    if (q) { q->qx = nanv; q->qy = nanv; q->qv = nanv; q->qth = nanv; }
+    if (!inside) return nanv;
+    int c[3];
+    float a[3], st[3], p[3][2];
+    for (int k = 0; k < 3; ++k) {
+        /* tf.where(grid <= x)[-1]: the last boundary not above x; clamped so that corner + 1 exists */
+        int ci = 0;
+        for (int i = 0; i < g_leaf.n[k]; ++i) if (g_leaf.grid[k][i] <= xc[k]) ci = i;
+        if (ci > g_leaf.n[k] - 2) ci = g_leaf.n[k] - 2;
+        c[k] = ci;
+        st[k] = g_leaf.grid[k][ci + 1] - g_leaf.grid[k][ci];
+        a[k] = xc[k] - g_leaf.grid[k][ci];
+        p[k][0] = (-1.0f * a[k]) + (1.0f * st[k]);      /* (-1)**(i+1) * (x - g) + (1 - i) * step, i = 0 */
+        p[k][1] = (1.0f * a[k]) + (0.0f * st[k]);       /* i = 1 */
+    }
+    const float cell = (st[0] * st[1]) * st[2];
+    float sum = 0.0f, ga[3] = {0.0f, 0.0f, 0.0f};
+    for (int i0 = 0; i0 < 2; ++i0)
+        for (int i1 = 0; i1 < 2; ++i1)
+            for (int i2 = 0; i2 < 2; ++i2) {
+                const float val = g_leaf.values[((size_t)(c[0] + i0) * g_leaf.n[1] + (c[1] + i1)) * g_leaf.n[2] + (c[2] + i2)];
+                const float pv01 = p[0][i0] * p[1][i1];
+                const float pv = pv01 * p[2][i2];
+                const float num = val * pv;
+                sum = sum + num / cell;
+                if (q) {
+                    const float g_num = 1.0f / cell;
+                    const float g_pv = g_num * val;
+                    const float g_p2 = g_pv * pv01;
+                    const float g_pv01 = g_pv * p[2][i2];
+                    const float g_p0 = g_pv01 * p[1][i1];
+                    const float g_p1 = g_pv01 * p[0][i0];
+                    ga[0] = ga[0] + g_p0 * (i0 ? 1.0f : -1.0f);
+                    ga[1] = ga[1] + g_p1 * (i1 ? 1.0f : -1.0f);
+                    ga[2] = ga[2] + g_p2 * (i2 ? 1.0f : -1.0f);
+                }
+            }
+    if (q) {
+        q->qx = ga[0];
+        q->qy = ga[1];
+        if (g_leaf.proj_kind == 1) { q->qv = ga[2] * sn; q->qth = (ga[2] * v) * cn; }
+        else { q->qv = ga[2]; q->qth = 0.0f; }
+    }
+    return sum;
+}
+
 float ocd_oracle_reward(const ocd_scenario_desc *d, const float *ws, const float *w,
                         float *feats_out, float *grad_out)
 {
@@ -354,8 +428,12 @@ static float mpc_reward_core(const ocd_scenario_desc *d, const float *ego, const
         dyn_fwd(x, y, v, th, c, s, u[2 * t], u[2 * t + 1], dt, dt2, f, &xn, &yn, &vn, &thn, &tape[t].dyn);
         float sn, cn;
         ocd_ref_sincosf(thn, &sn, &cn);
-        const float r = reward_state(d, w, xn, yn, vn, sn, cn, (const float (*)[2])oxy[t], NULL,
-                                     grad ? &tape[t].q : NULL);
+        float r;
+        if (g_leaf.values && t == H - 1)        /* naive_planner.py:69-70 */
+            r = leaf_value(xn, yn, vn, sn, cn, grad ? &tape[t].q : NULL);
+        else
+            r = reward_state(d, w, xn, yn, vn, sn, cn, (const float (*)[2])oxy[t], NULL,
+                             grad ? &tape[t].q : NULL);
         R = R + r;                              /* r = 0; r += reward_fn(...) */
         x = xn; y = yn; v = vn; th = thn; s = sn; c = cn;
         if (traj) { traj[4 * t] = x; traj[4 * t + 1] = y; traj[4 * t + 2] = v; traj[4 * t + 3] = th; }
@@ -479,7 +557,8 @@ static float run_steps(const ocd_scenario_desc *d, float *ws, const float *w_pla
     if (d->check_plans) {
         for (int j = 0; j < NO; ++j)
             for (int t = 0; t < H; ++t) {
-                const float *src = (t < d->other_plan_len[j]) ? d->other_plan[j][t] : d->other_default[j];
+                /* plan[j] if j < len(plan) else default_control if there is one else (0, 0) (planner_car.py:66-75) */
+                const float *src = (t < d->other_plan_len[j]) ? d->other_plan[j][t] : d->other_assumed_default[j];
                 oplans[(j * H + t) * 2] = src[0]; oplans[(j * H + t) * 2 + 1] = src[1];
             }
     }
@@ -554,7 +633,7 @@ int32_t ocd_rollout_episodes_cpu(const ocd_scenario_desc *d, const float *init_s
                                  const float *cand_weights, int64_t P, int64_t N,
                                  int64_t ep_begin, int64_t ep_end,
                                  float *returns_out, float *traj_out, float *ctrl_out,
-                                 int32_t n_threads)
+                                 int32_t n_threads, int32_t reset_phase)
 {
     if (!check_desc(d) || !init_states || !returns_out) return OCD_ERR_INVALID_ARG;
     const int64_t S = d->n_samples, E = P * N * S;
@@ -569,7 +648,10 @@ int32_t ocd_rollout_episodes_cpu(const ocd_scenario_desc *d, const float *init_s
     for (int64_t e = ep_begin; e < ep_end; ++e) {
         const int64_t s = e % S, n = (e / S) % N, p = e / (S * N);
         const int64_t o = e - ep_begin;
-        returns_out[o] = episode(d, init_states + 4 * n, cand_weights ? cand_weights + p * D : NULL, (int)s,
+        /* ReplanningCarWorld.reset() toggles the removed car on every reset (replanning_world.py:24-27):
+         * episode e of a sequential evaluation is reset number reset_phase + e */
+        const int tp = d->teleport_period > 0 ? (int)((reset_phase + e) % d->teleport_period) : (int)s;
+        returns_out[o] = episode(d, init_states + 4 * n, cand_weights ? cand_weights + p * D : NULL, tp,
                                  traj_out ? traj_out + o * (T + 1) * C * 4 : NULL,
                                  ctrl_out ? ctrl_out + o * T * 2 : NULL);
     }

@@ -50,6 +50,12 @@ float ocd_oracle_mpc_reward(const ocd_scenario_desc *d, const float *world_state
                             const float *weights, const float *controls,
                             const float *other_plans, float *grad_out, float *traj_out);
 
+/* Terminal value used by ocd_oracle_mpc_reward and the CPU twins below (process-global, test
+ * infrastructure): ocd_scenario_set_leaf_value of include/ocd.h; values == NULL removes it.
+ * The pointers are kept, not copied. */
+void ocd_oracle_set_leaf_value(const float *grid0, int32_t n0, const float *grid1, int32_t n1,
+                               const float *grid2, int32_t n2, const float *values, int32_t proj_kind);
+
 /* CPU twins of the device entry points of include/ocd.h (HOST pointers). */
 int32_t ocd_plan_batch_cpu(const ocd_scenario_desc *d,
                            const float *world_state,
@@ -65,7 +71,7 @@ int32_t ocd_rollout_episodes_cpu(const ocd_scenario_desc *d,
                                  int64_t P, int64_t N,
                                  int64_t ep_begin, int64_t ep_end,
                                  float *returns_out, float *traj_out, float *ctrl_out,
-                                 int32_t n_threads);
+                                 int32_t n_threads, int32_t reset_phase);
 
 int32_t ocd_rollout_from_state_cpu(const ocd_scenario_desc *d, const float *world_state,
                                    const float *weights, int32_t weights_per_problem,

@@ -90,7 +90,9 @@ class Oracle:
         lib.ocd_plan_batch_cpu.argtypes = [_D, _F, _F, C.c_int32, _F, _F, _F, _I, _F, _F, C.c_int64, C.c_int32]
         lib.ocd_rollout_episodes_cpu.restype = C.c_int32
         lib.ocd_rollout_episodes_cpu.argtypes = [_D, _F, _F, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
-                                                 _F, _F, _F, C.c_int32]
+                                                 _F, _F, _F, C.c_int32, C.c_int32]
+        lib.ocd_oracle_set_leaf_value.restype = None
+        lib.ocd_oracle_set_leaf_value.argtypes = [_F, C.c_int32, _F, C.c_int32, _F, C.c_int32, _F, C.c_int32]
         lib.ocd_rollout_from_state_cpu.restype = C.c_int32
         lib.ocd_rollout_from_state_cpu.argtypes = [_D, _F, _F, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                                    _F, _F, _F, C.c_int64]
@@ -173,7 +175,20 @@ class Oracle:
             raise RuntimeError(f"ocd_plan_batch_cpu -> {st}")
         return dict(plans=plans, best_loss=loss, best_init=best, all_plans=all_plans, all_losses=all_losses)
 
-    def rollout(self, desc, init_states, cand_weights, ep_begin=0, ep_end=None, want_traj=False, n_threads=0):
+    def set_leaf_value(self, disc_grid, values, proj_kind=0):
+        """Terminal value for every later call (process-global in the oracle); values=None removes it."""
+        if values is None:
+            self._leaf = None
+            self.lib.ocd_oracle_set_leaf_value(None, 0, None, 0, None, 0, None, 0)
+            return
+        g = [np.ascontiguousarray(a, dtype=self.real) for a in disc_grid]
+        v = np.ascontiguousarray(values, dtype=self.real)
+        self._leaf = (g, v)                      # the oracle keeps the pointers
+        self.lib.ocd_oracle_set_leaf_value(self._fp(g[0]), len(g[0]), self._fp(g[1]), len(g[1]),
+                                           self._fp(g[2]), len(g[2]), self._fp(v), int(proj_kind))
+
+    def rollout(self, desc, init_states, cand_weights, ep_begin=0, ep_end=None, want_traj=False, n_threads=0,
+                reset_phase=0):
         init = np.ascontiguousarray(init_states, dtype=self.real).reshape(-1, 4)
         N = init.shape[0]
         if cand_weights is None:
@@ -190,7 +205,7 @@ class Oracle:
         traj = np.zeros((n, T + 1, C_, 4), dtype=self.real) if want_traj else None
         ctrl = np.zeros((n, T, 2), dtype=self.real) if want_traj else None
         st = self.lib.ocd_rollout_episodes_cpu(self._d(desc), self._fp(init), self._fp(w), P, N, ep_begin, ep_end,
-                                               self._fp(ret), self._fp(traj), self._fp(ctrl), n_threads)
+                                               self._fp(ret), self._fp(traj), self._fp(ctrl), n_threads, reset_phase)
         if st != 0:
             raise RuntimeError(f"ocd_rollout_episodes_cpu -> {st}")
         return dict(returns=ret, traj=traj, ctrl=ctrl)

@@ -104,7 +104,23 @@ def test_argument_checks_precede_any_device_work():
     assert lib.ocd_rollout_episodes(h, p, p, 2, 3, 5, 5, p, None, None, None) == abi.OCD_OK               # empty range
     assert lib.ocd_rollout_from_state(h, p, p, 0, 0, 3, 9, p, None, None, 1, None) == abi.OCD_ERR_INVALID_ARG  # sample 9
     assert lib.ocd_dynamics_batch(None, p, 0.1, 0.01, 0.2, p, 4, None) == abi.OCD_ERR_INVALID_ARG
-    assert lib.ocd_set_option(b"segs_per_wave", 99) == abi.OCD_ERR_INVALID_ARG
-    assert lib.ocd_set_option(None, 1) == abi.OCD_ERR_INVALID_ARG
+    assert lib.ocd_scenario_set_option(h, b"segs_per_wave", 99) == abi.OCD_ERR_INVALID_ARG
+    assert lib.ocd_scenario_set_option(h, None, 1) == abi.OCD_ERR_INVALID_ARG
+    assert lib.ocd_scenario_set_option(None, b"scan_mode", 1) == abi.OCD_ERR_INVALID_ARG
+    assert lib.ocd_scenario_set_option(h, b"scan_mode", 3) == abi.OCD_OK              # per handle, no global state
+    assert lib.ocd_scenario_set_option(h, b"reset_phase", 1) == abi.OCD_OK
+    assert lib.ocd_mpc_reward_batch(h, p, p, 0, None, None, p, p, None, 1, None) == abi.OCD_ERR_INVALID_ARG  # controls NULL
+    # terminal-value table: argument checks run on the host
+    g = np.array([0.0, 1.0, 2.0], dtype=np.float32)
+    gp = g.ctypes.data_as(C.POINTER(C.c_float))
+    vals = np.zeros(27, dtype=np.float32)
+    vp = vals.ctypes.data_as(C.POINTER(C.c_float))
+    assert lib.ocd_scenario_set_leaf_value(h, gp, 3, gp, 3, gp, 3, vp, 7) == abi.OCD_ERR_INVALID_ARG   # proj_kind
+    assert lib.ocd_scenario_set_leaf_value(h, gp, 1, gp, 3, gp, 3, vp, 0) == abi.OCD_ERR_INVALID_ARG   # one grid point
+    bad = np.array([0.0, 2.0, 1.0], dtype=np.float32)
+    assert lib.ocd_scenario_set_leaf_value(h, bad.ctypes.data_as(C.POINTER(C.c_float)), 3, gp, 3, gp, 3, vp, 0) \
+        == abi.OCD_ERR_INVALID_ARG and b"ascending" in lib.ocd_last_error()
+    assert lib.ocd_scenario_set_leaf_value(h, gp, 3, gp, 3, gp, 3, vp, 1) == abi.OCD_OK
+    assert lib.ocd_scenario_set_leaf_value(h, None, 0, None, 0, None, 0, None, 0) == abi.OCD_OK        # remove
     lib.ocd_scenario_destroy(h)
     lib.ocd_scenario_destroy(None)                                                                        # no-op

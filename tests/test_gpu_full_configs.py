@@ -27,15 +27,13 @@ def _engine(scn):
     return Engine(scn, "cuda:0")
 
 
-@pytest.mark.parametrize("scan_mode", [1, 2])
+@pytest.mark.parametrize("scan_mode", [0, 1, 2, 3])
 def test_config3_every_episode_bitwise(hip, oracle, scan_mode):
     scn, inits, w32 = _inputs(3)
     ref = oracle.rollout(scn.desc, inits, w32, n_threads=THREADS)["returns"]
-    assert hip.ocd_set_option(b"scan_mode", scan_mode) == 0
-    try:
-        got = _engine(scn).rollout(inits, w32)["returns"]
-    finally:
-        hip.ocd_set_option(b"scan_mode", 0)
+    eng = _engine(scn)
+    eng.set_option("scan_mode", scan_mode)
+    got = eng.rollout(inits, w32)["returns"]
     assert got.shape == (64 * 32,) and np.array_equal(got, ref)
 
 
@@ -64,12 +62,13 @@ def test_configs_4_5_full_size(hip, oracle, cfg, n_sampled_ranges):
     perm = rng.permutation(P)
     permuted = eng.rollout(inits, w32[perm])["returns"].reshape(P, N * S)
     assert np.array_equal(permuted, full.reshape(P, N * S)[perm])
-    # every other launch shape on EVERY episode: one trajectory per wavefront, and (H <= 16) the DPP-row variant
-    shapes = [(1, 1)] + ([(2, 0), (2, 1)] if scn.desc.horizon <= 16 else [])
+    # every other launch shape on EVERY episode: one trajectory per wavefront, (H <= 16) the DPP-row variant,
+    # (K*H <= 64) all initialisations in one wavefront
+    shapes = [(1, 1)] + ([(2, 0), (2, 1)] if scn.desc.horizon <= 16 else []) + ([(3, 0)] if 3 * scn.desc.horizon <= 64 else [])
     for mode, segs in shapes:
-        assert hip.ocd_set_option(b"scan_mode", mode) == 0 and hip.ocd_set_option(b"segs_per_wave", segs) == 0
+        eng.set_option("scan_mode", mode); eng.set_option("segs_per_wave", segs)
         try:
             other = eng.rollout(inits, w32)["returns"]
         finally:
-            hip.ocd_set_option(b"segs_per_wave", 0); hip.ocd_set_option(b"scan_mode", 0)
+            eng.set_option("segs_per_wave", 0); eng.set_option("scan_mode", 0)
         assert np.array_equal(other, full), (mode, segs, np.nonzero(other != full)[0][:10])

@@ -155,12 +155,14 @@ def test_rollout_bitwise(oracle, eng_factory, name, H, P, N):
     assert out["returns"].shape == (P * N * scn.desc.n_samples,)
 
 
-@pytest.mark.parametrize("scan_mode", [1, 2])
+@pytest.mark.parametrize("scan_mode", [1, 2, 3])
 @pytest.mark.parametrize("name,H,n_iter", [("finite_horizon", 10, 40), ("replanning", 15, 25), ("merging", 5, 40),
-                                           ("local_opt", 16, 15), ("finite_horizon", 3, 30)])
-def test_both_scan_variants_bitwise(oracle, eng_factory, hip, scan_mode, name, H, n_iter):
-    """scan_mode 1 (LDS windows) and 2 (DPP row shifts, H <= 16) are two implementations of the same
-    recurrences; both must reproduce the oracle bit for bit, plans, losses and episodes."""
+                                           ("local_opt", 16, 15), ("finite_horizon", 3, 30), ("merging", 10, 20)])
+def test_all_scan_variants_bitwise(oracle, eng_factory, hip, scan_mode, name, H, n_iter):
+    """scan_mode 1 (LDS windows), 2 (DPP row shifts, H <= 16) and 3 (all K initialisations in one
+    wavefront, K*H <= 64) are three implementations of the same recurrences; all must reproduce the
+    oracle bit for bit, plans, losses and episodes.  (Horizons without a specialised kernel run the
+    generic LDS kernel whatever the mode.)"""
     scn = scenarios.SCENARIOS[name](horizon=H, n_iter=n_iter)
     eng = eng_factory(scn)
     B = 21
@@ -170,15 +172,15 @@ def test_both_scan_variants_bitwise(oracle, eng_factory, hip, scan_mode, name, H
     ref = oracle.plan_batch(scn.desc, ws, w, other_plans=scn.other_plans())
     inits = scn.init_dist.sample(3, seed=H + 5)
     rr = oracle.rollout(scn.desc, inits, w[:2], want_traj=True)
-    assert hip.ocd_set_option(b"scan_mode", scan_mode) == 0
+    eng.set_option("scan_mode", scan_mode)
     try:
         out = eng.plan_batch(ws, w, want_all=True)
         ro = eng.rollout(inits, w[:2], want_traj=True)
-        hip.ocd_set_option(b"segs_per_wave", 3)          # several trajectories per wavefront as well
+        eng.set_option("segs_per_wave", 3)          # several trajectories per wavefront as well
         out3 = eng.plan_batch(ws, w, want_all=True)
     finally:
-        hip.ocd_set_option(b"scan_mode", 0)
-        hip.ocd_set_option(b"segs_per_wave", 0)
+        eng.set_option("scan_mode", 0)
+        eng.set_option("segs_per_wave", 0)
     for o in (out, out3):
         assert_bitwise(o["all_losses"], ref["all_losses"], "losses"); assert_bitwise(o["all_plans"], ref["all_plans"], "plans")
         assert np.array_equal(o["best_init"], ref["best_init"]); assert_bitwise(o["best_loss"], ref["best_loss"], "best loss")
@@ -186,8 +188,8 @@ def test_both_scan_variants_bitwise(oracle, eng_factory, hip, scan_mode, name, H
     assert_bitwise(ro["returns"], rr["returns"], "returns")
 
 
-@pytest.mark.parametrize("segs", [1, 2, 6, 0])
-def test_results_do_not_depend_on_packing(oracle, eng_factory, hip, segs):
+@pytest.mark.parametrize("segs,mode", [(1, 0), (2, 0), (6, 1), (0, 0), (1, 3), (2, 3), (3, 2)])
+def test_results_do_not_depend_on_packing(oracle, eng_factory, hip, segs, mode):
     """segs_per_wave (trajectories per wavefront) is a pure performance knob: packed lanes, parked
     lanes and the wave-uniform feature skips must not change a bit."""
     scn = scenarios.finite_horizon(horizon=10, n_iter=40)
@@ -195,27 +197,29 @@ def test_results_do_not_depend_on_packing(oracle, eng_factory, hip, segs):
     ws = _world_states(scn, 29, seed=77)
     w = np.stack([scenarios.planner_weights_fp32(c) for c in scn.candidate_weights(29, seed=78)])
     ref = oracle.plan_batch(scn.desc, ws, w)
-    assert hip.ocd_set_option(b"segs_per_wave", segs) == 0
-    assert hip.ocd_set_option(b"scan_mode", 1 if segs == 6 else 0) == 0   # 6 per wavefront exists only with LDS windows
-    assert hip.ocd_set_option(b"no_feature_skips", segs % 2) == 0       # skips on and off
-    assert hip.ocd_set_option(b"no_unified_features", (segs // 2) % 2) == 0   # shared exp(-1/u) path on and off
+    eng.set_option("segs_per_wave", segs)
+    eng.set_option("scan_mode", mode)                  # 6 per wavefront exists only with LDS windows
+    eng.set_option("no_feature_skips", segs % 2)       # skips on and off
+    eng.set_option("no_unified_features", (segs // 2) % 2)   # shared exp(-1/u) path on and off
     try:
         out = eng.plan_batch(ws, w, want_all=True)
         inits = scn.init_dist.sample(5, seed=79)
         ro = eng.rollout(inits, w[:2], want_traj=True)
     finally:
-        hip.ocd_set_option(b"segs_per_wave", 0)
-        hip.ocd_set_option(b"no_feature_skips", 0)
-        hip.ocd_set_option(b"no_unified_features", 0)
-        hip.ocd_set_option(b"scan_mode", 0)
+        eng.set_option("segs_per_wave", 0)
+        eng.set_option("no_feature_skips", 0)
+        eng.set_option("no_unified_features", 0)
+        eng.set_option("scan_mode", 0)
     assert_bitwise(out["all_plans"], ref["all_plans"]); assert_bitwise(out["all_losses"], ref["all_losses"])
     rr = oracle.rollout(scn.desc, inits, w[:2], want_traj=True)
     assert_bitwise(ro["traj"], rr["traj"]); assert_bitwise(ro["returns"], rr["returns"])
-    assert hip.ocd_set_option(b"nonsense", 1) != 0
+    from l4dc_mpc_ocd_amd import abi
+    with pytest.raises(abi.OcdError):
+        eng.set_option("nonsense", 1)
 
 
-@pytest.mark.parametrize("segs", [1, 0, 6])
-def test_non_finite_trajectories_bitwise(oracle, eng_factory, hip, segs):
+@pytest.mark.parametrize("segs,mode", [(1, 0), (0, 0), (6, 1), (0, 1), (1, 3), (2, 3), (2, 2)])
+def test_non_finite_trajectories_bitwise(oracle, eng_factory, hip, segs, mode):
     """Hard braking drives v negative and the drag term -f*v^2 then runs away to -inf inside the
     horizon (car_dynamics_step has no speed floor): rewards become -inf, losses +inf, some adjoints
     NaN.  The kernels must reproduce the oracle through inf and NaN, in both scan variants."""
@@ -228,12 +232,13 @@ def test_non_finite_trajectories_bitwise(oracle, eng_factory, hip, segs):
     w = np.stack([scenarios.planner_weights_fp32(c) for c in scn.candidate_weights(B, seed=6)])
     ref = oracle.plan_batch(scn.desc, ws, w)
     assert np.isinf(ref["all_losses"]).any() or np.isnan(ref["all_losses"]).any()
-    assert hip.ocd_set_option(b"segs_per_wave", segs) == 0
+    eng.set_option("segs_per_wave", segs)
+    eng.set_option("scan_mode", mode)
     try:
         out = eng.plan_batch(ws, w, want_all=True)
         ro = eng.rollout_from_state(ws, w, first_step=0, n_steps=8)
     finally:
-        hip.ocd_set_option(b"segs_per_wave", 0)
+        eng.set_option("segs_per_wave", 0)
     assert_bitwise(out["all_losses"], ref["all_losses"], "losses")
     assert_bitwise(out["all_plans"], ref["all_plans"], "plans")
     assert np.array_equal(out["best_init"], ref["best_init"])
@@ -269,11 +274,10 @@ def test_baseline_config2_bitwise(oracle, eng_factory):
 def test_errors_are_reported_not_thrown(hip, eng_factory):
     import ctypes as C
     from l4dc_mpc_ocd_amd import abi
-    scn = scenarios.finite_horizon(horizon=7)            # no compiled kernel for H=7
-    eng = eng_factory(scn)
-    with pytest.raises(abi.OcdError) as ei:
-        eng.plan_batch(np.zeros((1, 2, 4), dtype=np.float32), scn.designer_weights)
-    assert ei.value.status == abi.OCD_ERR_UNSUPPORTED
+    bad = scenarios.finite_horizon(horizon=abi.OCD_MAX_HORIZON + 1).desc   # beyond the header limit
+    h = C.c_void_p()
+    assert hip.ocd_scenario_create(C.byref(bad), C.byref(h)) == abi.OCD_ERR_INVALID_ARG
+    assert b"horizon" in hip.ocd_last_error()
     bad = scenarios.finite_horizon(horizon=5).desc
     bad.n_cars = 9
     h = C.c_void_p()

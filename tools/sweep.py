@@ -18,7 +18,7 @@ def main():
     ap.add_argument("--pop-scale", type=int, default=1, help="multiply the population (bigger batches)")
     ap.add_argument("--no-skips", type=int, default=0)
     ap.add_argument("--no-unify", type=int, default=0)
-    ap.add_argument("--scan-mode", default="0", help="comma list of scan modes: 0 auto, 1 LDS windows, 2 DPP rows")
+    ap.add_argument("--scan-mode", default="0", help="comma list of scan modes: 0 auto, 1 LDS windows, 2 DPP rows, 3 all inits in one wavefront")
     a = ap.parse_args()
     import torch
     from l4dc_mpc_ocd_amd import scenarios
@@ -34,22 +34,20 @@ def main():
         w_dev = torch.as_tensor(w32).cuda()
         E = P * N * S
         ret = torch.empty(E, dtype=torch.float32, device="cuda")
-        eng.lib.ocd_set_option(b"no_feature_skips", a.no_skips)
-        eng.lib.ocd_set_option(b"no_unified_features", a.no_unify)
+        eng.set_option("no_feature_skips", a.no_skips)
+        eng.set_option("no_unified_features", a.no_unify)
         for mode in [int(m) for m in a.scan_mode.split(",")]:
-            if mode == 2 and c["horizon"] > 16:
+            if (mode == 2 and c["horizon"] > 16) or (mode == 3 and scn.desc.n_ctrl_inits * c["horizon"] > 64):
                 continue
-            assert eng.lib.ocd_set_option(b"scan_mode", mode) == 0
+            eng.set_option("scan_mode", mode)
             for segs in [int(s) for s in a.segs.split(",")]:
-                if mode == 2 and segs > 4:
+                if (mode == 2 and segs > 4) or (mode == 3 and segs > 64 // (scn.desc.n_ctrl_inits * c["horizon"])):
                     continue
-                assert eng.lib.ocd_set_option(b"segs_per_wave", segs) == 0
+                eng.set_option("segs_per_wave", segs)
                 eng.time_rollout(init_dev, w_dev, 0, E, ret, 1)
                 ms = eng.time_rollout(init_dev, w_dev, 0, E, ret, a.reps)
                 print(f"cfg{cfg} {c['scenario']} H={c['horizon']} E={E} scan_mode={mode} segs={segs}: {ms:.3f} ms/launch "
                       f"-> {E / ms * 1e3:.0f} episodes/s  checksum {float(ret.sum()):.6f}", flush=True)
-        eng.lib.ocd_set_option(b"segs_per_wave", 0)
-        eng.lib.ocd_set_option(b"scan_mode", 0)
 
 
 if __name__ == "__main__":
