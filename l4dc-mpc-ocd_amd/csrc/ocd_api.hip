@@ -38,6 +38,12 @@ struct ocd_scenario {
     int32_t n_cus[OCD_MAX_DEVICES];
 };
 
+#ifdef OCD_STAMPS
+// diagnostic build only (make stamps): where the kernels drop their per-wavefront cycle totals
+static unsigned long long *g_stamp_buf = nullptr;
+extern "C" void ocd_debug_set_stamp_buffer(void *dev_ptr) { g_stamp_buf = (unsigned long long *)dev_ptr; }
+#endif
+
 namespace {
 
 thread_local char g_err[512] = "";
@@ -150,6 +156,9 @@ int32_t launch(const ocd_scenario *scn, ocd::KernelParams &p, void *hip_stream)
 {
     int32_t ds = device_state(scn, (hipStream_t)hip_stream, p);
     if (ds != OCD_OK) return ds;
+#ifdef OCD_STAMPS
+    p.debug = g_stamp_buf;
+#endif
     bool supported = false;
     const int L = scn->desc.reward_kind == OCD_REWARD_LANE_FEATURES ? scn->desc.n_lanes : 0;
     hipError_t e = ocd::launch_mpc_dispatch(scn->desc.horizon, scn->desc.n_cars - 1, L, p, (hipStream_t)hip_stream, &supported);

@@ -1,0 +1,183 @@
+// ocd_chains.h -- hand-scheduled horizon recurrences of the DPP variants (V_ROW, V_SEG), gfx950.
+//
+// A lone wavefront issues one instruction per ~4.6 cycles whatever its dependencies (measured:
+// tools/microbench/valu_latency.hip), so a recurrence round costs its instruction count, s_nop
+// included.  hipcc neither fuses the add into the DPP move when the boundary lane has to keep its value
+// (v_add_f32_dpp with the destination tied as `old`), nor interleaves two chains so that each covers
+// the other's DPP hazard (a VGPR written by a VALU instruction needs 2 wait states before a DPP
+// instruction reads it).  Each recurrence below is ONE asm statement -- hipcc pads nothing inside it --
+// scheduled so that every DPP read comes >= 2 instructions after the write; the arithmetic is the
+// kernel's C++ formulation instruction for instruction (same operations, same operands, same order).
+//
+//   V_ROW: a trajectory owns a 16-lane row; row_shr:1 / row_shl:1 have no source in the row's first /
+//          last lane, which therefore keeps its value (bound_ctrl off): the boundary costs nothing.
+//   V_SEG: segments of H lanes anywhere in the wavefront; wave_shr:1 / wave_shl:1 cross segment
+//          boundaries, so the move is a v_cndmask_b32_dpp that selects the boundary value in the
+//          segment's first / last lane (VCC = boundary mask, loaded once per statement).
+//
+// The number of rounds is H-1: OCD_CHAIN_ROUNDS(HT, STMT) instantiates STMT with the repeat macro of the
+// specialised horizon.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define OCD_REP1(S) S
+#define OCD_REP2(S) S S
+#define OCD_REP4(S) S S S S
+#define OCD_REP5(S) S S S S S
+#define OCD_REP9(S) OCD_REP4(S) OCD_REP5(S)
+#define OCD_REP14(S) OCD_REP9(S) OCD_REP5(S)
+
+// STMT(REP) must expand to a statement using REP("...") for the round body
+#define OCD_CHAIN_ROUNDS(HT, STMT)                                   \
+    do {                                                             \
+        if constexpr ((HT) == 2) { STMT(OCD_REP1) }                  \
+        else if constexpr ((HT) == 3) { STMT(OCD_REP2) }             \
+        else if constexpr ((HT) == 5) { STMT(OCD_REP4) }             \
+        else if constexpr ((HT) == 6) { STMT(OCD_REP5) }             \
+        else if constexpr ((HT) == 10) { STMT(OCD_REP9) }            \
+        else if constexpr ((HT) == 15) { STMT(OCD_REP14) }           \
+        else static_assert((HT) == 2, "no repeat macro for this horizon"); \
+    } while (0)
+
+namespace ocd {
+
+template <int HT> struct chain_supported { static constexpr bool value = HT == 2 || HT == 3 || HT == 5 || HT == 6 || HT == 10 || HT == 15; };
+
+#define OCD_ROW_SHR " row_shr:1 row_mask:0xf bank_mask:0xf\n"
+#define OCD_ROW_SHL " row_shl:1 row_mask:0xf bank_mask:0xf\n"
+#define OCD_WAVE_SHR " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+#define OCD_WAVE_SHL " wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+
+// ---- forward speed / heading recurrence ----
+//   v_next = v + (a_c - fr * (v * v)) * dt ; th_next = th + wdt ; (v, th) <- (v_next, th_next) of the lane below
+// The heading chain runs half a round ahead of the speed chain (thn is the NEXT round's th_next), so its
+// two instructions fill the two wait states between the speed chain's add and its DPP move.
+template <int HT>
+__device__ __forceinline__ void row_fwd_vth(float &v, float &th, float a_c, float wdt, float fr, float dt)
+{
+    float thn = th + wdt, tmp;
+#define OCD_STMT(REP)                                                                                     \
+    asm volatile(REP("v_mul_f32 %[t], %[v], %[v]\n"                                                       \
+                     "v_mul_f32 %[t], %[fr], %[t]\n"                                                      \
+                     "v_sub_f32 %[t], %[ac], %[t]\n"                                                      \
+                     "v_mul_f32 %[t], %[dt], %[t]\n"                                                      \
+                     "v_add_f32 %[t], %[v], %[t]\n"                                                       \
+                     "v_mov_b32_dpp %[th], %[thn]" OCD_ROW_SHR                                            \
+                     "v_add_f32 %[thn], %[th], %[wdt]\n"                                                  \
+                     "v_mov_b32_dpp %[v], %[t]" OCD_ROW_SHR)                                              \
+                 : [v] "+v"(v), [th] "+v"(th), [thn] "+v"(thn), [t] "=&v"(tmp)                           \
+                 : [ac] "v"(a_c), [wdt] "v"(wdt), [fr] "s"(fr), [dt] "s"(dt));
+    OCD_CHAIN_ROUNDS(HT, OCD_STMT);
+#undef OCD_STMT
+}
+
+template <int HT>
+__device__ __forceinline__ void seg_fwd_vth(float &v, float &th, float ev, float eth, float a_c, float wdt, float fr,
+                                            float dt, unsigned long long first_mask)
+{
+    float thn = th + wdt, tmp;
+#define OCD_STMT(REP)                                                                                     \
+    asm volatile("s_mov_b64 vcc, %[m]\n"                                                                  \
+                 REP("v_mul_f32 %[t], %[v], %[v]\n"                                                       \
+                     "v_mul_f32 %[t], %[fr], %[t]\n"                                                      \
+                     "v_sub_f32 %[t], %[ac], %[t]\n"                                                      \
+                     "v_mul_f32 %[t], %[dt], %[t]\n"                                                      \
+                     "v_add_f32 %[t], %[v], %[t]\n"                                                       \
+                     "v_cndmask_b32_dpp %[th], %[thn], %[eth], vcc" OCD_WAVE_SHR                          \
+                     "v_add_f32 %[thn], %[th], %[wdt]\n"                                                  \
+                     "v_cndmask_b32_dpp %[v], %[t], %[ev], vcc" OCD_WAVE_SHR)                             \
+                 : [v] "+v"(v), [th] "+v"(th), [thn] "+v"(thn), [t] "=&v"(tmp)                           \
+                 : [ac] "v"(a_c), [wdt] "v"(wdt), [ev] "v"(ev), [eth] "v"(eth), [fr] "s"(fr), [dt] "s"(dt), \
+                   [m] "s"(first_mask)                                                                    \
+                 : "vcc");
+    OCD_CHAIN_ROUNDS(HT, OCD_STMT);
+#undef OCD_STMT
+}
+
+// ---- forward position recurrence:  x <- (x + cd) of the lane below, y <- (y + sd) of the lane below ----
+// V_ROW: fused into the DPP add with the increment of the lane below (cdb, sdb) brought up once:
+//        x[t] = x[t-1] + cd[t-1]; the row's lane 0 is not written and keeps ex.
+template <int HT>
+__device__ __forceinline__ void row_fwd_xy(float &x, float &y, float cdb, float sdb)
+{
+#define OCD_STMT(REP)                                                                                     \
+    asm volatile("s_nop 1\n"                                                                              \
+                 REP("v_add_f32_dpp %[x], %[x], %[cdb]" OCD_ROW_SHR                                       \
+                     "v_add_f32_dpp %[y], %[y], %[sdb]" OCD_ROW_SHR                                       \
+                     "s_nop 0\n")                                                                         \
+                 : [x] "+v"(x), [y] "+v"(y) : [cdb] "v"(cdb), [sdb] "v"(sdb));
+    OCD_CHAIN_ROUNDS(HT, OCD_STMT);
+#undef OCD_STMT
+}
+
+// V_SEG: the y chain runs half a round behind the x chain; each chain's add and select cover the other's hazard.
+template <int HT>
+__device__ __forceinline__ void seg_fwd_xy(float &x, float &y, float ex, float ey, float cd, float sd,
+                                           unsigned long long first_mask)
+{
+    float sx, sy = y + sd;
+#define OCD_STMT(REP)                                                                                     \
+    asm volatile("s_mov_b64 vcc, %[m]\n"                                                                  \
+                 REP("v_add_f32 %[sx], %[x], %[cd]\n"                                                     \
+                     "v_cndmask_b32_dpp %[y], %[sy], %[ey], vcc" OCD_WAVE_SHR                             \
+                     "v_add_f32 %[sy], %[y], %[sd]\n"                                                     \
+                     "v_cndmask_b32_dpp %[x], %[sx], %[ex], vcc" OCD_WAVE_SHR)                            \
+                 : [x] "+v"(x), [y] "+v"(y), [sx] "=&v"(sx), [sy] "+v"(sy)                               \
+                 : [cd] "v"(cd), [sd] "v"(sd), [ex] "v"(ex), [ey] "v"(ey), [m] "s"(first_mask)           \
+                 : "vcc");
+    OCD_CHAIN_ROUNDS(HT, OCD_STMT);
+#undef OCD_STMT
+}
+
+// ---- adjoint position recurrence (V_SEG):  Lx <- (qx + Lx) of the lane above, 0 in the segment's top lane ----
+template <int HT>
+__device__ __forceinline__ void seg_bwd_xy(float &Lx, float &Ly, float qx, float qy, unsigned long long last_mask)
+{
+    float ax, ay = qy + Ly;
+    const float zero = 0.0f;
+#define OCD_STMT(REP)                                                                                     \
+    asm volatile("s_mov_b64 vcc, %[m]\n"                                                                  \
+                 REP("v_add_f32 %[ax], %[qx], %[Lx]\n"                                                    \
+                     "v_cndmask_b32_dpp %[Ly], %[ay], %[z], vcc" OCD_WAVE_SHL                             \
+                     "v_add_f32 %[ay], %[qy], %[Ly]\n"                                                    \
+                     "v_cndmask_b32_dpp %[Lx], %[ax], %[z], vcc" OCD_WAVE_SHL)                            \
+                 : [Lx] "+v"(Lx), [Ly] "+v"(Ly), [ax] "=&v"(ax), [ay] "+v"(ay)                           \
+                 : [qx] "v"(qx), [qy] "v"(qy), [z] "v"(zero), [m] "s"(last_mask)                         \
+                 : "vcc");
+    OCD_CHAIN_ROUNDS(HT, OCD_STMT);
+#undef OCD_STMT
+}
+
+// ---- adjoint speed / heading recurrence (V_SEG) ----
+//   Av = qv + Lv ; gA = gA1 + Av*dt ; gv2 = (-gA)*fr ; gv3 = (gv2*2)*v ; Lv <- ((gv1 + Av) + gv3) of the lane above
+//   Lth <- ((qth + Lth) + tau) of the lane above ; both 0 in the segment's top lane.
+// The heading chain runs half a round ahead (ltd is the NEXT round's (qth + Lth) + tau).
+template <int HT>
+__device__ __forceinline__ void seg_bwd_vth(float &Lv, float &Lth, float qv, float qth, float gA1, float gv1, float v,
+                                            float tau, float fr, float dt, unsigned long long last_mask)
+{
+    float ltd = (qth + Lth) + tau, av, s, g;
+    const float zero = 0.0f;
+#define OCD_STMT(REP)                                                                                     \
+    asm volatile("s_mov_b64 vcc, %[m]\n"                                                                  \
+                 REP("v_add_f32 %[av], %[qv], %[Lv]\n"                                                    \
+                     "v_add_f32 %[s], %[gv1], %[av]\n"                                                    \
+                     "v_mul_f32 %[g], %[dt], %[av]\n"                                                     \
+                     "v_add_f32 %[g], %[gA1], %[g]\n"                                                     \
+                     "v_mul_f32_e64 %[g], -%[g], %[fr]\n"                                                 \
+                     "v_add_f32 %[g], %[g], %[g]\n"                                                       \
+                     "v_mul_f32 %[g], %[g], %[v]\n"                                                       \
+                     "v_add_f32 %[s], %[s], %[g]\n"                                                       \
+                     "v_cndmask_b32_dpp %[Lth], %[ltd], %[z], vcc" OCD_WAVE_SHL                           \
+                     "v_add_f32 %[ltd], %[qth], %[Lth]\n"                                                 \
+                     "v_add_f32 %[ltd], %[ltd], %[tau]\n"                                                 \
+                     "v_cndmask_b32_dpp %[Lv], %[s], %[z], vcc" OCD_WAVE_SHL)                             \
+                 : [Lv] "+v"(Lv), [Lth] "+v"(Lth), [ltd] "+v"(ltd), [av] "=&v"(av), [s] "=&v"(s), [g] "=&v"(g) \
+                 : [qv] "v"(qv), [qth] "v"(qth), [gA1] "v"(gA1), [gv1] "v"(gv1), [v] "v"(v), [tau] "v"(tau), \
+                   [z] "v"(zero), [fr] "s"(fr), [dt] "s"(dt), [m] "s"(last_mask)                          \
+                 : "vcc");
+    OCD_CHAIN_ROUNDS(HT, OCD_STMT);
+#undef OCD_STMT
+}
+
+} // namespace ocd

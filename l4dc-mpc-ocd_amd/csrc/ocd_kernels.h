@@ -59,6 +59,7 @@ struct KernelParams {
     int32_t scan_mode;         // 0 = automatic, 1 = V_LDS, 2 = V_ROW, 3 = V_SEG
     int32_t no_unify;          // diagnostics: 1 = never use the one-feature-per-lane evaluation
     int32_t n_cus;             // compute units of the device (launch shape heuristics)
+    unsigned long long *debug; // diagnostic builds only (OCD_STAMPS): per-wavefront cycle totals, else nullptr
 };
 
 // (horizon H, scripted cars NO, lanes L) triples with a planner kernel specialised on H (loops fully

@@ -38,6 +38,7 @@
 #include <type_traits>
 
 #include "../../include/ocd.h"
+#include "ocd_chains.h"
 #include "ocd_device.h"
 #include "ocd_kernels.h"
 
@@ -113,12 +114,27 @@ __device__ __forceinline__ float lane_read(float v, int src_lane)
 
 template <bool B> using bool_c = std::integral_constant<bool, B>;
 
+// In-kernel cycle stamps (diagnostic build only: make STAMPS=1; never shipped).  Section totals of
+// wavefront (block, wave) go to p.debug[(block * K + wave) * 16 + section]; no output depends on them.
+#ifdef OCD_STAMPS
+#define OCD_STAMP_DECL unsigned long long st_acc[16] = {0}, st_last = __builtin_amdgcn_s_memtime();
+#define OCD_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long st_now = __builtin_amdgcn_s_memtime(); \
+                          __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); st_acc[i] += st_now - st_last; st_last = st_now; } while (0)
+#define OCD_STAMP_COUNT(i) do { st_acc[i] += 1; } while (0)
+#else
+#define OCD_STAMP_DECL
+#define OCD_STAMP(i) do { } while (0)
+#define OCD_STAMP_COUNT(i) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------- the kernel
-template <int HT, int NO, int L, int V>
+// LEAF: the terminal-value lookup (leaf_evaluation) is compiled into the generic kernel only.
+template <int HT, int NO, int L, int V, bool LEAF = false>
 __global__ void __launch_bounds__(V == V_SEG ? 64 : 64 * OCD_MAX_CTRL_INITS)
 mpc_kernel(const KernelParams p)
 {
     static_assert(HT > 0 || V == V_LDS, "the generic (run-time H) kernel exchanges through LDS");
+    static_assert(!LEAF || HT == 0, "the terminal value runs in the generic kernel");
     static_assert(V != V_ROW || HT <= 16, "V_ROW keeps a trajectory inside one 16-lane DPP row");
     constexpr int NOA = NO > 0 ? NO : 1;
     constexpr bool lane_feats = L > 0;
@@ -136,6 +152,8 @@ mpc_kernel(const KernelParams p)
     const int t = (V == V_ROW) ? (lane & 15) : (lane - seg * H);
     const bool in_h = t < H;                                      // V_ROW: lanes H..15 of a row idle along
     const bool first = t == 0, last = t == H - 1;
+    const unsigned long long first_mask = __ballot(first), last_mask = __ballot(last);
+    constexpr bool asm_chains = (V != V_LDS) && chain_supported<HT>::value;   // hand-scheduled recurrences (ocd_chains.h)
     // trajectory slot inside the wavefront and control initialisation this lane works for
     const int slot = (V == V_SEG) ? (seg / K) : seg;
     const int kinit = (V == V_SEG) ? (seg - slot * K) : wave;
@@ -220,10 +238,11 @@ mpc_kernel(const KernelParams p)
     for (int k = 0; k < OCD_MAX_FEATURES; ++k) wd[k] = d.designer_weights[k];
 
     const int T = p.T;
+    OCD_STAMP_DECL
     float G_ret = 0.0f;
     const BumpGeom bg0 = {0.0f, 1.0f, 0.0f, 1.0f};
     const bool writer = live && kinit == 0 && first;          // one lane per trajectory writes its outputs
-    const bool has_leaf = p.leaf.values != nullptr;           // terminal value replaces the last step's reward
+    constexpr bool has_leaf = LEAF;                           // terminal value replaces the last step's reward
     LeafTable leaf;
     leaf.grid = p.leaf.grid; leaf.values = p.leaf.values; leaf.proj_kind = p.leaf.proj_kind;
     leaf.n[0] = p.leaf.n[0]; leaf.n[1] = p.leaf.n[1]; leaf.n[2] = p.leaf.n[2];
@@ -319,6 +338,7 @@ mpc_kernel(const KernelParams p)
         // one pass over the horizon: GRAD = an SGD step on (ua, uw); !GRAD = the objective only (loss)
         auto horizon_pass = [&](auto grad_tag) __attribute__((always_inline)) {
             constexpr bool GRAD = decltype(grad_tag)::value;
+            OCD_STAMP(0);                                  // everything outside the passes
             // ===== forward =====
             const float a1 = min_tf(ua, 4.0f);
             const float a_c = max_tf(a1, -8.0f);
@@ -329,7 +349,10 @@ mpc_kernel(const KernelParams p)
             const float wdt = w_c * dt;
 
             float v = ev, th = eth;
-            if (V == V_ROW) {
+            if constexpr (asm_chains) {
+                if (V == V_ROW) row_fwd_vth<HT>(v, th, a_c, wdt, fr, dt);
+                else seg_fwd_vth<HT>(v, th, ev, eth, a_c, wdt, fr, dt, first_mask);
+            } else if (V == V_ROW) {
                 // every lane advances its own state by its own control and hands the result to the lane
                 // above; after t rounds lane t holds the state before step t (lane 0 keeps the current state)
 #pragma unroll
@@ -369,6 +392,7 @@ mpc_kernel(const KernelParams p)
                     }
                 }
             }
+            OCD_STAMP(1);                                  // speed / heading recurrence
             // own step t: (v, th) is the state before it
             const float v2 = v * v;
             const float fv2 = fr * v2;
@@ -393,8 +417,12 @@ mpc_kernel(const KernelParams p)
             }
             const float cd = c_pre * dd;
             const float sd = s_pre * dd;
+            OCD_STAMP(2);                                  // own step, sincos
             float x = ex, y = ey;
-            if (V == V_ROW) {
+            if constexpr (asm_chains) {
+                if (V == V_ROW) row_fwd_xy<HT>(x, y, row_below(0.0f, cd), row_below(0.0f, sd));
+                else seg_fwd_xy<HT>(x, y, ex, ey, cd, sd, first_mask);
+            } else if (V == V_ROW) {
 #pragma unroll
                 for (int i = 0; i < H - 1; ++i) {
                     x = row_below(x, x + cd);              // lane 0 keeps ex
@@ -420,6 +448,7 @@ mpc_kernel(const KernelParams p)
             }
             const float xn = x + cd;
             const float yn = y + sd;
+            OCD_STAMP(3);                                  // position recurrence
 
             // ===== reward features at the post-step state =====
             // wave-uniform choice of the evaluation: none of {fence, collisions} active on any live lane /
@@ -440,17 +469,21 @@ mpc_kernel(const KernelParams p)
                     mc_any |= mj;
                 }
                 const bool has_f = mf != 0ull, has_col = mc_any != 0ull;
+                OCD_STAMP(4);                              // choice of the evaluation
                 if (p.no_skips || multi != 0ull || (p.no_unify && (has_f || has_col))) {
                     r = reward_state<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, true, true);
+                    OCD_STAMP(5); OCD_STAMP_COUNT(12);     // every feature
                 } else if (has_f || has_col) {
                     r = reward_one<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, nc, nf, has_col, has_f, q);
+                    OCD_STAMP(6); OCD_STAMP_COUNT(13);     // one feature per lane
                 } else {
                     r = reward_state<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, false, false);
+                    OCD_STAMP(7); OCD_STAMP_COUNT(14);     // neither fence nor collision
                 }
             } else {
                 r = reward_state<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr);
             }
-            if (has_leaf) {                                // naive_planner.py:69-70
+            if constexpr (has_leaf) {                      // naive_planner.py:69-70
                 Q4 ql;
                 const float rl_ = leaf_value<GRAD>(leaf, xn, yn, vn, sn, cn, ql);
                 r = last ? rl_ : r;
@@ -504,6 +537,8 @@ mpc_kernel(const KernelParams p)
                         Lx = qx_a + row_above(0.0f, Lx);
                         Ly = qy_a + row_above(0.0f, Ly);
                     }
+                } else if (V == V_SEG && asm_chains) {
+                    if constexpr (asm_chains) seg_bwd_xy<HT>(Lx, Ly, q.qx, q.qy, last_mask);
                 } else if (V == V_SEG) {
 #pragma unroll
                     for (int i = 0; i < H - 1; ++i) {
@@ -522,6 +557,7 @@ mpc_kernel(const KernelParams p)
                         Ly = qq.y + Ly;
                     }
                 }
+                OCD_STAMP(8);                              // position adjoint recurrence
                 const float Ax = q.qx + Lx;
                 const float Ay = q.qy + Ly;
                 const float g_c = Ax * dd;
@@ -547,6 +583,8 @@ mpc_kernel(const KernelParams p)
                         Lv = row_above(0.0f, Lv_down);
                         Lth = (qth_a + row_above(0.0f, Lth)) + tau_a;
                     }
+                } else if (V == V_SEG && asm_chains) {
+                    if constexpr (asm_chains) seg_bwd_vth<HT>(Lv, Lth, q.qv, q.qth, gA1, gv1, v, tau, fr, dt, last_mask);
                 } else if (V == V_SEG) {
 #pragma unroll
                     for (int i = 0; i < H - 1; ++i) {
@@ -578,6 +616,7 @@ mpc_kernel(const KernelParams p)
                         Lth = Ath_ + a.y;
                     }
                 }
+                OCD_STAMP(9);                              // Jacobian products, speed / heading adjoint recurrence
                 const float Av = q.qv + Lv;
                 const float gA = gA1 + Av * dt;
                 const float Ath = q.qth + Lth;
@@ -587,6 +626,7 @@ mpc_kernel(const KernelParams p)
                 ua = ua + lr * grad_a;
                 uw = uw + lr * grad_w;
                 if (V == V_LDS) __builtin_amdgcn_wave_barrier();
+                OCD_STAMP(10);                             // control update
             }
         };
 
@@ -677,6 +717,11 @@ mpc_kernel(const KernelParams p)
         }
     }
     if (p.mode == OCD_MODE_ROLLOUT && writer) p.returns_out[prob] = G_ret;
+#ifdef OCD_STAMPS
+    OCD_STAMP(0);
+    if (p.debug && lane == 0)
+        for (int i = 0; i < 16; ++i) p.debug[((size_t)blockIdx.x * (V == V_SEG ? 1 : K) + wave) * 16 + i] = st_acc[i];
+#endif
 }
 
 // ---------------------------------------------------------------- small kernels
@@ -865,7 +910,8 @@ static hipError_t launch_mpc(const KernelParams &p_in, hipStream_t st)
     const int seg_cap = (HT > 0 && K * H <= 64) ? 64 / (K * H) : 0;    // V_SEG trajectories per wavefront
     const int row_cap = (HT > 0 && H <= 16) ? 4 : 0;                   // V_ROW
     int variant = V_LDS;
-    if (p.scan_mode == 2 && row_cap) variant = V_ROW;
+    if (p.leaf.values) variant = V_LDS;                                // the terminal value lives in the generic kernel
+    else if (p.scan_mode == 2 && row_cap) variant = V_ROW;
     else if (p.scan_mode == 3 && seg_cap) variant = V_SEG;
     else if (p.scan_mode == 0) {
         if (row_cap && n * K <= simds) variant = V_ROW;
@@ -890,7 +936,8 @@ static hipError_t launch_mpc(const KernelParams &p_in, hipStream_t st)
         }
     }
     const size_t lds = ((size_t)K * G.WAVE_FLOATS + (size_t)2 * K * G.SEL_FLOATS) * sizeof(float);
-    hipLaunchKernelGGL((mpc_kernel<HT, NO, L, V_LDS>), dim3(blocks), dim3(64 * K), lds, st, p);
+    if (p.leaf.values) hipLaunchKernelGGL((mpc_kernel<0, NO, L, V_LDS, true>), dim3(blocks), dim3(64 * K), lds, st, p);
+    else hipLaunchKernelGGL((mpc_kernel<HT, NO, L, V_LDS>), dim3(blocks), dim3(64 * K), lds, st, p);
     return hipGetLastError();
 }
 

@@ -1,0 +1,120 @@
+// Microbenchmark: issue / dependency cost of the VALU patterns the planner kernel is made of, for ONE
+// wavefront alone on its SIMD (the small-batch regime) and for 2 wavefronts on one SIMD.
+//   build: hipcc -O3 --offload-arch=gfx950 valu_latency.hip -o valu_latency ; run: ./valu_latency
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define REP8(S) S S S S S S S S
+#define REP64(S) REP8(REP8(S))
+
+template <int MODE>
+__global__ void bench(float *out, long long *cyc, int iters)
+{
+    float a = threadIdx.x * 1e-3f + 1.0f, b = a + 1.0f, c = a + 2.0f, d = a + 3.0f;
+    const float k = 0.999f, m = 1e-4f;
+    long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; ++i) {
+        if (MODE == 0) {          // 64 dependent fma
+            asm volatile(REP64("v_fma_f32 %0, %0, %1, %2\n") : "+v"(a) : "v"(k), "v"(m));
+        } else if (MODE == 1) {   // 2 independent chains, 32 each
+            asm volatile(REP8(REP8("v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3\n")) : "+v"(a), "+v"(b) : "v"(k), "v"(m));
+        } else if (MODE == 2) {   // 4 independent chains
+            asm volatile(REP8(REP8("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n"))
+                         : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(k), "v"(m));
+        } else if (MODE == 3) {   // dependent add_dpp row_shr chain with the required s_nop 1
+            asm volatile(REP64("v_add_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n s_nop 1\n") : "+v"(a) : "v"(m));
+        } else if (MODE == 4) {   // two interleaved add_dpp chains + s_nop 0 (the x/y recurrence)
+            asm volatile(REP64("v_add_f32_dpp %0, %0, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %1, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n s_nop 0\n")
+                         : "+v"(a), "+v"(b) : "v"(m));
+        } else if (MODE == 5) {   // dependent v_rcp chain
+            asm volatile(REP64("v_rcp_f32 %0, %0\n") : "+v"(a));
+        } else if (MODE == 6) {   // dependent mul chain
+            asm volatile(REP64("v_mul_f32 %0, %0, %1\n") : "+v"(a) : "v"(k));
+        } else if (MODE == 7) {   // wave_shr add chain
+            asm volatile(REP64("v_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n s_nop 1\n") : "+v"(a) : "v"(m));
+        } else if (MODE == 8) {   // s_nop 0 only
+            asm volatile(REP64("s_nop 0\n"));
+        } else if (MODE == 9) {   // full IEEE division, dependent chain (compiler sequence)
+#pragma unroll
+            for (int j = 0; j < 64; ++j) a = b / a;
+        } else if (MODE == 10) {  // cndmask_dpp select chain (V_SEG boundary form)
+            asm volatile(REP64("v_add_f32 %1, %0, %2\n s_nop 1\n v_cndmask_b32_dpp %0, %1, %2, vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n")
+                         : "+v"(a), "+v"(b) : "v"(m) : "vcc");
+        } else if (MODE == 11) {  // dependent v_cndmask
+            asm volatile(REP64("v_cndmask_b32 %0, %0, %1, vcc\n") : "+v"(a) : "v"(m) : "vcc");
+        } else if (MODE == 12) {  // SALU chain
+            int s = iters;
+            asm volatile(REP64("s_add_u32 %0, %0, 1\n") : "+s"(s));
+            if (s == 12345) a += 1.0f;
+        } else if (MODE == 13) {  // ds_bpermute dependent chain
+#pragma unroll
+            for (int j = 0; j < 64; ++j) a = __int_as_float(__builtin_amdgcn_ds_bpermute(((threadIdx.x + 1) & 63) << 2, __float_as_int(a)));
+        }
+    }
+    long long t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a + b + c + d;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+// whole-chip load: `blocks` single-wavefront workgroups; cycles per op (s_memtime) and ns per op (events)
+template <int MODE>
+void run_grid(const char *name, int ops_per_iter, int blocks, int threads)
+{
+    float *out; long long *cyc;
+    hipMalloc(&out, (size_t)blocks * threads * sizeof(float)); hipMalloc(&cyc, blocks * sizeof(long long));
+    const int iters = 20000;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    bench<MODE><<<blocks, threads>>>(out, cyc, iters);
+    hipEventRecord(e0);
+    bench<MODE><<<blocks, threads>>>(out, cyc, iters);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    std::vector<long long> h(blocks); hipMemcpy(h.data(), cyc, blocks * sizeof(long long), hipMemcpyDeviceToHost);
+    double mean = 0; for (auto v : h) mean += v; mean /= blocks;
+    const double ops = (double)iters * ops_per_iter;
+    printf("%-30s grid %5d x %3d thr: %.2f memtime-cycles/op, %.3f ns/op wall -> %.2f GHz-equivalent\n", name, blocks, threads,
+           mean / ops, ms * 1e6 / ops, (mean / ops) / (ms * 1e6 / ops));
+    hipFree(out); hipFree(cyc);
+}
+
+template <int MODE>
+void run(const char *name, int ops_per_iter, int waves)
+{
+    float *out; long long *cyc;
+    hipMalloc(&out, 1024 * sizeof(float)); hipMalloc(&cyc, 16 * sizeof(long long));
+    const int iters = 2000;
+    bench<MODE><<<1, 64 * waves>>>(out, cyc, iters);
+    bench<MODE><<<1, 64 * waves>>>(out, cyc, iters);
+    hipDeviceSynchronize();
+    long long h = 0; hipMemcpy(&h, cyc, sizeof(h), hipMemcpyDeviceToHost);
+    printf("%-46s waves/CU %d: %.2f cycles per op\n", name, waves, (double)h / ((double)iters * ops_per_iter));
+    hipFree(out); hipFree(cyc);
+}
+
+int main()
+{
+    for (int blocks : {1, 256, 1024, 2048, 4096}) run_grid<0>("dependent v_fma_f32", 64, blocks, 64);
+    for (int blocks : {256, 1024, 2048}) run_grid<9>("dependent IEEE division", 64, blocks, 64);
+    for (int blocks : {256, 1024, 2048}) run_grid<4>("x/y round (2 add_dpp + nop)", 64, blocks, 64);
+    for (int blocks : {256, 512}) run_grid<0>("dependent v_fma_f32", 64, blocks, 192);
+
+    for (int waves : {1, 4, 8}) {   // 1 wave; 4 waves = 1 per SIMD; 8 = 2 per SIMD
+        run<0>("dependent v_fma_f32", 64, waves);
+        run<1>("2 independent fma chains (per instr)", 128, waves);
+        run<2>("4 independent fma chains (per instr)", 256, waves);
+        run<6>("dependent v_mul_f32", 64, waves);
+        run<3>("dep. v_add_f32_dpp row_shr + s_nop 1 (per pair)", 64, waves);
+        run<7>("dep. v_add_f32_dpp wave_shr + s_nop 1 (per pair)", 64, waves);
+        run<4>("x/y round: 2 add_dpp + s_nop 0 (per round)", 64, waves);
+        run<10>("add + s_nop 1 + cndmask_dpp wave_shr (per round)", 64, waves);
+        run<11>("dependent v_cndmask_b32", 64, waves);
+        run<5>("dependent v_rcp_f32", 64, waves);
+        run<9>("dependent IEEE division a = b / a", 64, waves);
+        run<8>("s_nop 0", 64, waves);
+        run<12>("dependent s_add_u32", 64, waves);
+        run<13>("dependent ds_bpermute_b32", 64, waves);
+    }
+    return 0;
+}

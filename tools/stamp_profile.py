@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Where a wavefront's cycles go: runs one generation of a BASELINE config on the diagnostic build
+(`make -C l4dc-mpc-ocd_amd/csrc stamps`: in-kernel s_memtime stamps, ~10 % slower, never shipped) and
+prints the per-section cycle totals of the slowest, the median and the fastest wavefront.
+usage: python tools/stamp_profile.py --config 2 [--scan-mode 0] [--segs 0]"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+SECTIONS = ["outside the passes", "v/heading recurrence", "own step + sincos", "x/y recurrence",
+            "evaluation choice (ballots)", "features: everything", "features: one per lane", "features: none active",
+            "x/y adjoint recurrence", "Jacobian + v/heading adjoint rec.", "control update", "-",
+            "#passes everything", "#passes one-per-lane", "#passes none", "-"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, default=2)
+    ap.add_argument("--scan-mode", type=int, default=0)
+    ap.add_argument("--segs", type=int, default=0)
+    ap.add_argument("--no-skips", type=int, default=0)
+    a = ap.parse_args()
+    os.environ["OCD_HIP_LIB"] = os.path.join(ROOT, "l4dc-mpc-ocd_amd", "csrc", "libocd_hip_stamps.so")
+    import torch
+    from l4dc_mpc_ocd_amd import scenarios
+    from l4dc_mpc_ocd_amd.engine import Engine
+    scn, inits, cands = scenarios.baseline_config(a.config)
+    w32 = np.stack([scenarios.planner_weights_fp32(c) for c in cands])
+    eng = Engine(scn, "cuda:0")
+    eng.set_option("scan_mode", a.scan_mode)
+    eng.set_option("segs_per_wave", a.segs)
+    eng.set_option("no_feature_skips", a.no_skips)
+    E = w32.shape[0] * inits.shape[0] * scn.desc.n_samples
+    nw = E * scn.desc.n_ctrl_inits + 64
+    buf = torch.zeros(nw * 16, dtype=torch.int64, device="cuda:0")
+    eng.lib.ocd_debug_set_stamp_buffer.argtypes = [C.c_void_p]
+    eng.lib.ocd_debug_set_stamp_buffer(buf.data_ptr())
+    eng.rollout(inits, w32)
+    st = buf.cpu().numpy().reshape(nw, 16)
+    st = st[st[:, :11].sum(1) > 0]
+    tot = st[:, :11].sum(1)
+    order = np.argsort(tot)
+    picks = [("slowest", order[-1]), ("median", order[len(order) // 2]), ("fastest", order[0])]
+    print(f"config {a.config} scan_mode {a.scan_mode} segs {a.segs}: {len(st)} wavefronts, "
+          f"T*(n_iter+1) = {scn.desc.episode_len * (scn.desc.n_iter + 1)} passes each")
+    print(f"{'section':<36}" + "".join(f"{n:>22}" for n, _ in picks))
+    npass = scn.desc.episode_len * (scn.desc.n_iter + 1)
+    for i, name in enumerate(SECTIONS):
+        if name == "-":
+            continue
+        row = f"{name:<36}"
+        for _, w in picks:
+            v = int(st[w, i])
+            row += f"{v:>12d}" + (f" ({v / npass:7.1f})" if i < 11 else " " * 10)
+        print(row)
+    print(f"{'total cycles (per pass)':<36}" + "".join(f"{int(tot[w]):>12d} ({tot[w] / npass:7.1f})" for _, w in picks))
+
+
+if __name__ == "__main__":
+    main()
