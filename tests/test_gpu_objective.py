@@ -1,0 +1,144 @@
+"""GPU parity of the planner's objective and gradient for caller-supplied controls
+(ocd_mpc_reward_batch = NaivePlanner.reward_func + GradientTape, naive_planner.py:33-77,124-125) and of
+the terminal value (leaf_evaluation = ValueFeature.interpolate_value, value_interpolation.py:28-61;
+naive_planner.py:69-70), HIP path vs CPU oracle, bit for bit."""
+import numpy as np
+import pytest
+
+from l4dc_mpc_ocd_amd import scenarios
+
+pytestmark = pytest.mark.gpu
+
+
+def same(a, b, what=""):
+    a = np.asarray(a, dtype=np.float32); b = np.asarray(b, dtype=np.float32)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    ok = (a == b) | (np.isnan(a) & np.isnan(b))
+    assert ok.all(), f"{what}: {(~ok).sum()} of {a.size} differ, e.g. {a[~ok][:3]} vs {b[~ok][:3]}"
+
+
+def world_states(scn, n, seed):
+    rng = np.random.default_rng(seed)
+    d = scn.desc
+    ws = np.zeros((n, d.n_cars, 4))
+    for j in range(1, d.n_cars):
+        ws[:, j, :] = np.array(d.other_init[j - 1][:])
+    ws[:, 0, :] = scn.init_dist.sample(n, seed=seed + 1)
+    ws[:, 0, 0] += rng.uniform(-0.12, 0.12, n)
+    ws[:, 0, 3] += rng.uniform(-0.3, 0.3, n)
+    m = n // 3                        # a third of the states start inside a scripted car's collision bump
+    ws[:m, 0, 0] = ws[:m, 1, 0] + rng.uniform(-0.07, 0.07, m)
+    ws[:m, 0, 1] = ws[:m, 1, 1] + rng.uniform(-0.3, 0.05, m)
+    return ws.astype(np.float32)
+
+
+def controls(n, H, seed):
+    rng = np.random.default_rng(seed)
+    u = np.stack([rng.uniform(-2, 2, (n, H)), rng.uniform(-1.5, 1.5, (n, H))], axis=-1)
+    u[::4, :, 0] = rng.uniform(3.5, 6.0, (len(u[::4]), H))      # beyond the +4 clip: zero gradient there
+    u[1::4, :, 0] = rng.uniform(-10.0, -7.0, (len(u[1::4]), H))  # beyond the -8 clip
+    u[2::4, :, 1] = rng.uniform(3.0, 5.0, (len(u[2::4]), H))     # steering clip
+    u[3, :, 0] = 4.0                                              # exactly on the clip: Minimum passes the gradient
+    return u.astype(np.float32)
+
+
+@pytest.mark.parametrize("name,H", [("finite_horizon", 5), ("local_opt", 10), ("replanning", 15), ("merging", 25),
+                                    ("finite_horizon", 7), ("merging", 32)])
+def test_objective_and_gradient_bitwise(oracle, name, H):
+    from l4dc_mpc_ocd_amd.engine import Engine
+    scn = scenarios.SCENARIOS[name](horizon=H)
+    eng = Engine(scn, "cuda:0")
+    B = 40
+    ws = world_states(scn, B, seed=H)
+    u = controls(B, H, seed=H + 1)
+    w = np.stack([scenarios.planner_weights_fp32(c) for c in scn.candidate_weights(B, seed=H + 2)])
+    out = eng.mpc_reward_batch(ws, w, u, want_traj=True)
+    op = scn.other_plans()
+    for b in range(B):
+        r, g, tr = oracle.mpc_reward(scn.desc, ws[b], w[b], u[b], other_plans=op)
+        same(out["reward"][b], r, f"R[{b}]"); same(out["grad"][b], g, f"dR/du[{b}]"); same(out["traj"][b], tr, f"traj[{b}]")
+    assert np.any(out["grad"] == 0.0) and np.any(out["grad"] != 0.0)        # clipped and unclipped controls both present
+    # shared weights and a single control sequence broadcast over the batch
+    out1 = eng.mpc_reward_batch(ws, w[0], u[:1], want_grad=False)
+    for b in range(0, B, 7):
+        r, _, _ = oracle.mpc_reward(scn.desc, ws[b], w[0], u[0], other_plans=op, want_grad=False)
+        same(out1["reward"][b], r)
+
+
+def test_objective_is_what_the_planner_minimises(oracle):
+    """loss of generate_plan == -reward_func(plan): the two entry points agree on the same controls."""
+    from l4dc_mpc_ocd_amd.engine import Engine
+    scn = scenarios.finite_horizon(horizon=10, n_iter=25)
+    eng = Engine(scn, "cuda:0")
+    ws = world_states(scn, 12, seed=3)
+    w = np.stack([scenarios.planner_weights_fp32(c) for c in scn.candidate_weights(12, seed=4)])
+    plan = eng.plan_batch(ws, w)
+    obj = eng.mpc_reward_batch(ws, w, plan["plans"], want_grad=False)
+    same(-obj["reward"], plan["best_loss"], "loss vs -R")
+
+
+def value_table(seed, n=(7, 9, 6)):
+    rng = np.random.default_rng(seed)
+    grid = [np.linspace(-0.25, 0.25, n[0]), np.sort(rng.uniform(-2.4, 2.0, n[1])), np.linspace(0.0, 2.5, n[2])]
+    grid[1][0], grid[1][-1] = -2.4, 2.0
+    vals = rng.standard_normal(n).astype(np.float32) * 3 - 2
+    return [g.astype(np.float32) for g in grid], vals
+
+
+@pytest.mark.parametrize("proj_kind", [0, 1])
+@pytest.mark.parametrize("name,H", [("finite_horizon", 5), ("local_opt", 10), ("merging", 12)])
+def test_terminal_value_bitwise(oracle, name, H, proj_kind):
+    """leaf_evaluation: objective, gradient, plans and episodes with a trilinear value table."""
+    from l4dc_mpc_ocd_amd.engine import Engine
+    scn = scenarios.SCENARIOS[name](horizon=H, n_iter=20)
+    eng = Engine(scn, "cuda:0")
+    grid, vals = value_table(H + proj_kind)
+    eng.set_leaf_value(grid, vals, proj_kind)
+    oracle.set_leaf_value(grid, vals, proj_kind)
+    try:
+        B = 24
+        ws = world_states(scn, B, seed=H + 5)
+        ws[:4, 0, 1] = 5.0                                       # outside the y grid: NaN like the reference
+        u = controls(B, H, seed=H + 6) * 0.3
+        w = np.stack([scenarios.planner_weights_fp32(c) for c in scn.candidate_weights(B, seed=H + 7)])
+        out = eng.mpc_reward_batch(ws, w, u, want_traj=True)
+        for b in range(B):
+            r, g, tr = oracle.mpc_reward(scn.desc, ws[b], w[b], u[b])
+            same(out["reward"][b], r, f"R[{b}]"); same(out["grad"][b], g, f"grad[{b}]")
+        assert np.isnan(out["reward"][:4]).all() and np.isfinite(out["reward"][4:]).sum() >= 6
+        ref = oracle.plan_batch(scn.desc, ws, w)
+        got = eng.plan_batch(ws, w, want_all=True)
+        same(got["all_losses"], ref["all_losses"], "losses"); same(got["all_plans"], ref["all_plans"], "plans")
+        assert np.array_equal(got["best_init"], ref["best_init"])
+        inits = scn.init_dist.sample(3, seed=9)
+        ro = eng.rollout(inits, w[:2], want_traj=True)
+        rr = oracle.rollout(scn.desc, inits, w[:2], want_traj=True)
+        same(ro["ctrl"], rr["ctrl"], "ctrl"); same(ro["traj"], rr["traj"], "traj"); same(ro["returns"], rr["returns"], "returns")
+        # removing the table restores the plain objective
+        eng.set_leaf_value(None, None)
+        oracle.set_leaf_value(None, None)
+        got0 = eng.plan_batch(ws[4:], w[4:])
+        ref0 = oracle.plan_batch(scn.desc, ws[4:], w[4:])
+        same(got0["plans"], ref0["plans"], "plans without the table")
+        assert not np.array_equal(got0["plans"], got["plans"][4:])
+    finally:
+        oracle.set_leaf_value(None, None)
+
+
+def test_teleport_cycle_follows_the_flat_episode_index(oracle):
+    """ReplanningCarWorld.reset() toggles the removed car on every reset (replanning_world.py:24-27): with one
+    sample per init consecutive inits lose different cars, and reset_phase shifts the cycle."""
+    from l4dc_mpc_ocd_amd.engine import Engine
+    scn = scenarios.replanning(horizon=5)
+    scn.desc.n_samples = 1
+    eng = Engine(scn, "cuda:0")
+    inits = scn.init_dist.sample(3, seed=2)
+    w = np.stack([scenarios.planner_weights_fp32(c) for c in scn.candidate_weights(2, seed=3)])
+    for phase in (0, 1):
+        eng.set_option("reset_phase", phase)
+        out = eng.rollout(inits, w, want_traj=True)
+        ref = oracle.rollout(scn.desc, inits, w, want_traj=True, reset_phase=phase)
+        same(out["traj"], ref["traj"]); same(out["returns"], ref["returns"])
+        gone = out["traj"][:, -1, 1:, 0] == 10.0                  # which scripted car sits at x = 10 at the end
+        assert gone.sum(axis=1).tolist() == [1] * 6
+        assert gone[:, 0].tolist() == [(phase + e) % 2 == 0 for e in range(6)]

@@ -8,9 +8,13 @@ from l4dc_mpc_ocd_amd import abi, scenarios
 
 pytestmark = pytest.mark.gpu
 
-# (H, scripted cars, lanes) triples with a compiled kernel (subset of OCD_KERNEL_TABLE)
-SHAPES = [(3, 1, 3), (5, 1, 3), (8, 1, 3), (10, 1, 3), (16, 1, 3), (20, 1, 3), (5, 2, 2), (10, 2, 2), (15, 2, 2),
-          (3, 2, 3), (8, 2, 3), (10, 2, 3), (25, 2, 3), (5, 3, 3)]
+# (H, scripted cars, lanes): EVERY planning horizon 1..OCD_MAX_HORIZON (the reference takes any,
+# naive_planner.py:19-26), cycling through 1-3 scripted cars x 1-4 lanes; horizons with a specialised
+# kernel (OCD_KERNEL_TABLE) appear with their own (cars, lanes) pairs as well.
+_PAIRS = [(1, 3), (2, 2), (2, 3), (3, 3), (1, 2), (3, 2), (1, 1), (2, 4), (1, 4), (3, 1), (2, 1), (3, 4)]
+SHAPES = [(H, *_PAIRS[H % len(_PAIRS)]) for H in range(1, abi.OCD_MAX_HORIZON + 1)] + \
+         [(5, 1, 3), (6, 1, 3), (10, 1, 3), (15, 1, 3), (25, 1, 3), (5, 2, 2), (10, 2, 2), (15, 2, 2),
+          (5, 2, 3), (10, 2, 3), (25, 2, 3)]
 
 
 def random_scenario(rng, H, NO, L):
@@ -24,6 +28,7 @@ def random_scenario(rng, H, NO, L):
     d.episode_len = int(rng.integers(2, 7))
     d.n_samples = int(rng.integers(1, 3))
     d.teleport_step = int(rng.integers(0, 4))
+    d.teleport_period = int(rng.integers(0, abi.OCD_MAX_SAMPLES + 1))
     for s in range(abi.OCD_MAX_SAMPLES):
         d.teleport_car[s] = int(rng.integers(1, NO + 1)) if rng.random() < 0.7 else -1
     dt = float(rng.choice([0.05, 0.1, 0.2]))
@@ -50,6 +55,10 @@ def random_scenario(rng, H, NO, L):
         for t in range(n_plan):
             d.other_plan[j][t][0], d.other_plan[j][t][1] = rng.uniform(-1, 1), rng.uniform(-3, 3)
         d.other_default[j][0], d.other_default[j][1] = rng.uniform(-0.2, 0.2), rng.uniform(-0.5, 0.5)
+        if rng.random() < 0.5:      # what a check_plans planner assumes beyond the plan (planner_car.py:66-75)
+            d.other_assumed_default[j][0], d.other_assumed_default[j][1] = d.other_default[j][0], d.other_default[j][1]
+        else:
+            d.other_assumed_default[j][0], d.other_assumed_default[j][1] = 0.0, 0.0
     w = rng.standard_normal(L + 4)
     w[L + 1:] = -np.abs(w[L + 1:]) * 3            # collision / fence / min-lane are costs, as in the reference
     w32 = (w / np.linalg.norm(w)).astype(np.float32)
@@ -59,7 +68,7 @@ def random_scenario(rng, H, NO, L):
     return scn
 
 
-@pytest.mark.parametrize("case", range(len(SHAPES) * 2))
+@pytest.mark.parametrize("case", range(len(SHAPES) + 20))
 def test_random_descriptor_bitwise(hip, oracle, case):
     from l4dc_mpc_ocd_amd.engine import Engine
     H, NO, L = SHAPES[case % len(SHAPES)]
@@ -67,6 +76,9 @@ def test_random_descriptor_bitwise(hip, oracle, case):
     scn = random_scenario(rng, H, NO, L)
     d = scn.desc
     eng = Engine(scn, "cuda:0")
+    eng.set_option("scan_mode", int(rng.integers(0, 4)))            # any variant the shape allows
+    phase = int(rng.integers(0, 3))
+    eng.set_option("reset_phase", phase)
     B = int(rng.integers(1, 12))
     ws = np.zeros((B, NO + 1, 4), dtype=np.float32)
     ws[:, 0, 0] = rng.uniform(-0.2, 0.2, B); ws[:, 0, 1] = rng.uniform(-1.4, -0.5, B)
@@ -84,7 +96,7 @@ def test_random_descriptor_bitwise(hip, oracle, case):
     assert np.array_equal(out["best_init"], ref["best_init"])
     inits = ws[: min(B, 3), 0]
     ro = eng.rollout(inits, w32[:2], want_traj=True)
-    rr = oracle.rollout(d, inits, w32[:2], want_traj=True)
+    rr = oracle.rollout(d, inits, w32[:2], want_traj=True, reset_phase=phase)
     for k in ("ctrl", "traj", "returns"):
         a, b = ro[k], rr[k]
         assert a.shape == b.shape and np.all((a == b) | (np.isnan(a) & np.isnan(b))), (scn.name, k)

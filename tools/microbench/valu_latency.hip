@@ -13,6 +13,8 @@ __global__ void bench(float *out, long long *cyc, int iters)
 {
     float a = threadIdx.x * 1e-3f + 1.0f, b = a + 1.0f, c = a + 2.0f, d = a + 3.0f;
     const float k = 0.999f, m = 1e-4f;
+    typedef float float2v __attribute__((ext_vector_type(2)));
+    float2v pa = {a, b}, pk = {k, k}, pm = {m, m};
     long long t0 = __builtin_amdgcn_s_memtime();
     for (int i = 0; i < iters; ++i) {
         if (MODE == 0) {          // 64 dependent fma
@@ -47,13 +49,21 @@ __global__ void bench(float *out, long long *cyc, int iters)
             int s = iters;
             asm volatile(REP64("s_add_u32 %0, %0, 1\n") : "+s"(s));
             if (s == 12345) a += 1.0f;
+        } else if (MODE == 14) {  // dependent v_pk_fma_f32 chain (2 floats per lane per instruction)
+            asm volatile(REP64("v_pk_fma_f32 %0, %0, %1, %2\n") : "+v"(pa) : "v"(pk), "v"(pm));
+        } else if (MODE == 15) {  // dependent v_pk_mul_f32
+            asm volatile(REP64("v_pk_mul_f32 %0, %0, %1\n") : "+v"(pa) : "v"(pk));
+        } else if (MODE == 16) {  // dependent v_pk_add_f32
+            asm volatile(REP64("v_pk_add_f32 %0, %0, %1\n") : "+v"(pa) : "v"(pm));
+        } else if (MODE == 17) {  // pk_fma alternating with a plain fma on other registers
+            asm volatile(REP64("v_pk_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %4, %5\n") : "+v"(pa), "+v"(b) : "v"(pk), "v"(pm), "v"(k), "v"(m));
         } else if (MODE == 13) {  // ds_bpermute dependent chain
 #pragma unroll
             for (int j = 0; j < 64; ++j) a = __int_as_float(__builtin_amdgcn_ds_bpermute(((threadIdx.x + 1) & 63) << 2, __float_as_int(a)));
         }
     }
     long long t1 = __builtin_amdgcn_s_memtime();
-    out[blockIdx.x * blockDim.x + threadIdx.x] = a + b + c + d;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a + b + c + d + pa.x + pa.y;
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
@@ -100,7 +110,7 @@ int main()
     for (int blocks : {256, 1024, 2048}) run_grid<4>("x/y round (2 add_dpp + nop)", 64, blocks, 64);
     for (int blocks : {256, 512}) run_grid<0>("dependent v_fma_f32", 64, blocks, 192);
 
-    for (int waves : {1, 4, 8}) {   // 1 wave; 4 waves = 1 per SIMD; 8 = 2 per SIMD
+    for (int waves : {1, 8}) {   // 1 wave; 4 waves = 1 per SIMD; 8 = 2 per SIMD
         run<0>("dependent v_fma_f32", 64, waves);
         run<1>("2 independent fma chains (per instr)", 128, waves);
         run<2>("4 independent fma chains (per instr)", 256, waves);
@@ -115,6 +125,10 @@ int main()
         run<8>("s_nop 0", 64, waves);
         run<12>("dependent s_add_u32", 64, waves);
         run<13>("dependent ds_bpermute_b32", 64, waves);
+        run<14>("dependent v_pk_fma_f32", 64, waves);
+        run<15>("dependent v_pk_mul_f32", 64, waves);
+        run<16>("dependent v_pk_add_f32", 64, waves);
+        run<17>("pk_fma + fma alternating (per pair)", 64, waves);
     }
     return 0;
 }
