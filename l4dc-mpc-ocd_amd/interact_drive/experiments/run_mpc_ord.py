@@ -36,6 +36,19 @@ envs = {
 }
 
 
+def make_mpc_ord(scenario, horizon=None, n_inits=1, seed=1, save_path=None):
+    """MPC_ORD over `scenario` at an arbitrary planning horizon with `n_inits` synthetic init states
+    (scenarios.InitDistribution.sample: the seeded inverse-CDF sampler of the benchmark configs)."""
+    from ._build import world_from_scenario
+    from .replanning_world import ReplanningCarWorld
+    scn = scenarios.SCENARIOS[scenario](**({} if horizon is None else {"horizon": horizon}))
+    init_states = list(scn.init_dist.sample(n_inits, seed=seed))
+    world_cls = ReplanningCarWorld if scenario == "replanning" else None
+    car, _, world = world_from_scenario(scn, init_states[0], debug=True, world_cls=world_cls)
+    return MPC_ORD(world, car, init_states, scn.desc.episode_len, save_path=save_path,
+                   num_samples=scn.desc.n_samples)
+
+
 def run_opt(env, init_states, args, optimization_seed):
     car, world, _ = env['make_env'](debug=True)
     save_path = (f'{args.optimizer}_{args.scenario}__designer_weights_{fmt(car.weights)}__'

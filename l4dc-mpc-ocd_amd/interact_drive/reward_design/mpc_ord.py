@@ -23,6 +23,27 @@ class list2(list):  # mutable list that can carry a .seed attribute (mpc_ord.py:
         super().__init__(*args, **kwargs)
 
 
+def _pickle_as_reference_list2():
+    """History pickles must load in the reference's own scripts (bar_plot.py:105-130, generalization_plot.py:
+    167-177 unpickle `interact_drive.reward_design.mpc_ord.list2`): pickle the class under the reference's
+    module path, and make that path resolve to this mirror in this process unless the real package is there."""
+    import importlib
+    import sys
+    ref = "interact_drive.reward_design.mpc_ord"
+    here = sys.modules[__name__]
+    pkg_rd = sys.modules[__name__.rsplit(".", 1)[0]]
+    pkg_id = sys.modules[__name__.rsplit(".", 2)[0]]
+    try:
+        mod = importlib.import_module(ref)          # the real reference is installed: its class wins
+        if getattr(mod, "list2", None) is not list2 and mod is not here:
+            return
+    except Exception:
+        sys.modules.setdefault("interact_drive", pkg_id)
+        sys.modules.setdefault("interact_drive.reward_design", pkg_rd)
+        sys.modules.setdefault(ref, here)
+    list2.__module__ = ref
+
+
 class MPC_ORD:
     def __init__(self, world, car, init_car_states, designer_horizon, save_path=None, num_samples=1):
         self.world = world
@@ -164,6 +185,9 @@ class MPC_ORD:
         assert self.save_path is not None
         with open(self.save_path, 'wb') as file:
             pickle.dump(self.history, file)
+
+
+_pickle_as_reference_list2()
 
 
 def finite_horizon_env(horizon=5, env_seeds=[1], debug=True, extra_inits=False):

@@ -131,6 +131,33 @@ def test_cmaes_minimises_a_quadratic():
     assert es.best_f < 1e-8 and np.allclose(es.mean, 0.25, atol=1e-3)
 
 
+def test_history_pickle_loads_in_the_reference(tmp_path):
+    """bar_plot.py:105-130 unpickles interact_drive.reward_design.mpc_ord.list2: the pickle must name that
+    path, and load in a process that only has the reference's module tree (simulated by a stub)."""
+    import subprocess
+    import sys
+    from l4dc_mpc_ocd_amd.interact_drive.reward_design.mpc_ord import list2
+    h = list2()
+    h.seed = 7
+    h.append((np.arange(3.0), -2.5))
+    p = tmp_path / "hist.pkl"
+    with open(p, "wb") as f:
+        pickle.dump(h, f)
+    raw = p.read_bytes()
+    assert b"interact_drive.reward_design.mpc_ord" in raw and b"l4dc" not in raw
+    stub = tmp_path / "ref" / "interact_drive" / "reward_design"
+    stub.mkdir(parents=True)
+    (tmp_path / "ref" / "interact_drive" / "__init__.py").write_text("")
+    (stub / "__init__.py").write_text("")
+    (stub / "mpc_ord.py").write_text("class list2(list):\n    def __init__(self, *a, **k):\n        super().__init__(*a, **k)\n")
+    code = ("import pickle, sys; sys.path.insert(0, sys.argv[1]); h = pickle.load(open(sys.argv[2], 'rb')); "
+            "print(type(h).__module__, h.seed, h[0][1], [float(v) for v in h[0][0]])")
+    r = subprocess.run([sys.executable, "-c", code, str(tmp_path / "ref"), str(p)], capture_output=True, text=True,
+                       cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.split() == ["interact_drive.reward_design.mpc_ord", "7", "-2.5", "[0.0,", "1.0,", "2.0]"]
+
+
 def test_history_pickle_format(tmp_path):
     h = __import__("l4dc_mpc_ocd_amd.interact_drive.reward_design.mpc_ord", fromlist=["list2"]).list2()
     h.seed = 5
