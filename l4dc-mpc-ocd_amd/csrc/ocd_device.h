@@ -312,7 +312,8 @@ template <int NO, int L, bool GRAD>
 __device__ __forceinline__ float reward_one(const ocd_scenario_desc &d, const float (&w)[OCD_MAX_FEATURES],
                                             float x, float y, float v, float sn, float cn,
                                             const BumpGeom (&bg)[NO > 0 ? NO : 1], const bool (&nc)[NO > 0 ? NO : 1],
-                                            const bool is_f, const bool has_col, const bool has_f, Q4 &q)
+                                            const bool is_f, const bool has_col, const bool has_f, Q4 &q,
+                                            const PkConsts &pkc)
 {
     static_assert(L > 0 && NO > 0, "lane-feature reward only");
     const float tgt = d.target_speed;
@@ -354,10 +355,15 @@ __device__ __forceinline__ float reward_one(const ocd_scenario_desc &d, const fl
     bool condx = false, condy = false;
     float xcx = 0.0f, xcy = 0.0f;
     if (has_col) {
+#ifdef OCD_NO_PACKED
         const float znx = (x - g.cx) / g.wx;
+        const float zny = (y - g.cy) / g.wy;
+#else
+        const v2f ZN = div2_(v2f{x - g.cx, y - g.cy}, v2f{g.wx, g.wy});
+        const float znx = ZN.x, zny = ZN.y;
+#endif
         condx = (znx * znx) < 1.0f;
         xcx = condx ? znx : 0.0f;
-        const float zny = (y - g.cy) / g.wy;
         condy = (zny * zny) < 1.0f;
         xcy = condy ? zny : 0.0f;
     }
@@ -365,8 +371,15 @@ __device__ __forceinline__ float reward_one(const ocd_scenario_desc &d, const fl
     const float u1 = is_f ? uf1 : (1.0f - xcx * xcx);
     const float u2 = is_f ? uf2 : (1.0f - xcy * xcy);
     const float addc = is_f ? 0.0f : 1.0f;
+#ifdef OCD_NO_PACKED
     const float m1 = -1.0f / u1, m2 = -1.0f / u2;
     const float e1 = exp_le1(m1 + addc), e2 = exp_le1(m2 + addc);
+#else
+    const v2f U = {u1, u2};
+    const v2f M = div2_(splat2(-1.0f), U);
+    const v2f E = exp_le1_2(M + splat2(addc), pkc);
+    const float m1 = M.x, m2 = M.y, e1 = E.x, e2 = E.y;
+#endif
     // fence outputs (meaningful on fence lanes)
     float den = 1.0f, S = 0.0f, Ssum = 0.0f, ax = 0.0f, pf = 0.0f;
     if (has_f) {
@@ -393,7 +406,12 @@ __device__ __forceinline__ float reward_one(const ocd_scenario_desc &d, const fl
         return r;
     }
 
+#ifdef OCD_NO_PACKED
     const float k1 = (-m1) / u1, k2 = (-m2) / u2;
+#else
+    const v2f Kk = div2_(-M, U);
+    const float k1 = Kk.x, k2 = Kk.y;
+#endif
     const float g_sq = pass0 ? w[0] : 0.0f;
     const float g_dv = (g_sq * 2.0f) * dv;
     q.qv = g_dv * sn;
@@ -429,8 +447,13 @@ __device__ __forceinline__ float reward_one(const ocd_scenario_desc &d, const fl
     const float g_Ssum = w_f * ax;
     const float g_ax = w_f * Ssum;
     // the two shared division slots
+#ifdef OCD_NO_PACKED
     const float q1 = (is_f ? g_Ssum : g_znx) / (is_f ? den : g.wx);   // g_S/den           | g_zn_x / width_x
     const float q2 = (is_f ? -S : g_zny) / (is_f ? den : g.wy);       // (-S)/den          | g_zn_y / width_y
+#else
+    const v2f Q = div2_(v2f{is_f ? g_Ssum : g_znx, is_f ? -S : g_zny}, v2f{is_f ? den : g.wx, is_f ? den : g.wy});
+    const float q1 = Q.x, q2 = Q.y;
+#endif
     float qx_f = qx;
     if (has_f) {
         const float g_den = g_Ssum * q2;

@@ -81,6 +81,90 @@ __device__ __forceinline__ float exp_le1(float x)
     return (x >= -87.0f) ? res : 0.0f;
 }
 
+// ---- two-wide forms: the SAME operations on two independent values per lane through v_pk_* instructions.
+// A lone wavefront issues a packed fp32 instruction at the cost of a scalar one (tools/microbench/
+// valu_latency.hip).  The packed runs are inline asm: hipcc pads every dependent pair of packed
+// instructions with an s_nop that the hardware does not need (tools/microbench/pk_hazard.hip: the
+// unpadded chain is bit-identical to the scalar one on every lane), which would eat the gain.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f splat2(float v) { return v2f{v, v}; }
+
+// IEEE-correct fp32 division of two independent quotients: hipcc's own expansion (v_div_scale, v_rcp, the
+// Newton-Raphson refinement, v_div_fmas, v_div_fixup) with the six refinement operations packed.  The
+// result of a correctly rounded division does not depend on the instruction sequence.
+__device__ __forceinline__ v2f div2_(v2f n, v2f d)
+{
+    bool f0, f1, g0, g1;
+    v2f ds, ns, r, e, q;
+    ds.x = __builtin_amdgcn_div_scalef(n.x, d.x, false, &g0);
+    ds.y = __builtin_amdgcn_div_scalef(n.y, d.y, false, &g1);
+    ns.x = __builtin_amdgcn_div_scalef(n.x, d.x, true, &f0);
+    ns.y = __builtin_amdgcn_div_scalef(n.y, d.y, true, &f1);
+    r.x = __builtin_amdgcn_rcpf(ds.x);
+    r.y = __builtin_amdgcn_rcpf(ds.y);
+    // s_nop 0: a v_rcp_f32 result needs one wait state before a non-transcendental instruction reads it
+    asm("s_nop 0\n"
+        "v_pk_fma_f32 %[e], %[ds], %[r], 1.0 op_sel_hi:[1,1,0] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"   // 1 - ds*r
+        "v_pk_fma_f32 %[r], %[e], %[r], %[r]\n"                                                  // refined reciprocal
+        "v_pk_mul_f32 %[q], %[ns], %[r]\n"
+        "v_pk_fma_f32 %[e], %[ds], %[q], %[ns] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+        "v_pk_fma_f32 %[q], %[e], %[r], %[q]\n"
+        "v_pk_fma_f32 %[e], %[ds], %[q], %[ns] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+        : [e] "=&v"(e), [r] "+v"(r), [q] "=&v"(q) : [ds] "v"(ds), [ns] "v"(ns));
+    v2f out;
+    out.x = __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(e.x, r.x, q.x, f0), d.x, n.x);
+    out.y = __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(e.y, r.y, q.y, f1), d.y, n.y);
+    return out;
+}
+
+// Constants of exp_le1_2, two per VGPR pair (a packed instruction picks the low or the high dword of a
+// source for both of its lanes through op_sel / op_sel_hi).  Built once per kernel and pinned in registers.
+struct PkConsts { v2f a, b, c, d, e, f; };
+
+__device__ __forceinline__ PkConsts pk_consts()
+{
+    PkConsts k;
+    k.a = v2f{1.44269502162933349609375f, 12582912.0f};      // log2(e)        | 1.5 * 2^23
+    k.b = v2f{-12582912.0f, -0.693359375f};                   // -1.5 * 2^23    | -ln2 (high part)
+    k.c = v2f{2.12194440e-4f, 1.9875691500e-4f};              // ln2 (low part) | c5
+    k.d = v2f{1.3981999507e-3f, 8.3334519073e-3f};            // c4 | c3
+    k.e = v2f{4.1665795894e-2f, 1.6666665459e-1f};            // c2 | c1
+    k.f = v2f{5.0000001201e-1f, 0.0f};                        // c0 | -
+    asm volatile("" : "+v"(k.a), "+v"(k.b), "+v"(k.c), "+v"(k.d), "+v"(k.e), "+v"(k.f));   // keep, do not rematerialise
+    return k;
+}
+
+// exp_le1 of two values: the reduction and the polynomial packed (same operations as exp_le1, element-wise)
+__device__ __forceinline__ v2f exp_le1_2(v2f x, const PkConsts &k)
+{
+    v2f xs, n, r, p, e;
+    xs.x = (x.x >= -87.0f) ? x.x : -87.0f;
+    xs.y = (x.y >= -87.0f) ? x.y : -87.0f;
+    asm("v_pk_mul_f32 %[n], %[xs], %[A] op_sel_hi:[1,0]\n"                        // xs * log2(e)
+        "v_pk_add_f32 %[n], %[n], %[A] op_sel:[0,1] op_sel_hi:[1,1]\n"            // + 1.5*2^23  } round to nearest-even
+        "v_pk_add_f32 %[n], %[n], %[B] op_sel_hi:[1,0]\n"                         // - 1.5*2^23  } integer
+        "v_pk_fma_f32 %[r], %[n], %[B], %[xs] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n" // n * -ln2_hi + xs
+        "v_pk_fma_f32 %[r], %[n], %[C], %[r] op_sel_hi:[1,0,1]\n"                 // n * ln2_lo + r
+        "v_pk_fma_f32 %[p], %[C], %[r], %[D] op_sel:[1,0,0] op_sel_hi:[1,1,0]\n"   // c5 * r + c4
+        "v_pk_fma_f32 %[p], %[p], %[r], %[D] op_sel:[0,0,1] op_sel_hi:[1,1,1]\n"   // p * r + c3
+        "v_pk_fma_f32 %[p], %[p], %[r], %[E] op_sel_hi:[1,1,0]\n"                 // p * r + c2
+        "v_pk_fma_f32 %[p], %[p], %[r], %[E] op_sel:[0,0,1] op_sel_hi:[1,1,1]\n"   // p * r + c1
+        "v_pk_fma_f32 %[p], %[p], %[r], %[F] op_sel_hi:[1,1,0]\n"                 // p * r + c0
+        "v_pk_mul_f32 %[e], %[r], %[r]\n"
+        "v_pk_fma_f32 %[e], %[p], %[e], %[r]\n"
+        "v_pk_add_f32 %[e], %[e], 1.0 op_sel_hi:[1,0]\n"
+        : [n] "=&v"(n), [r] "=&v"(r), [p] "=&v"(p), [e] "=&v"(e)
+        : [xs] "v"(xs), [A] "v"(k.a), [B] "v"(k.b), [C] "v"(k.c), [D] "v"(k.d), [E] "v"(k.e), [F] "v"(k.f));
+    v2f scale;
+    scale.x = __int_as_float(((int32_t)n.x + 127) << 23);
+    scale.y = __int_as_float(((int32_t)n.y + 127) << 23);
+    v2f out;
+    out.x = (x.x >= -87.0f) ? (e.x * scale.x) : 0.0f;
+    out.y = (x.y >= -87.0f) ? (e.y * scale.y) : 0.0f;
+    return out;
+}
+
 __device__ __forceinline__ void sincos_(float x, float &s_out, float &c_out)
 {
     const float n = rint_small(x * 0.636619746685028076171875f);

@@ -238,6 +238,7 @@ mpc_kernel(const KernelParams p)
     for (int k = 0; k < OCD_MAX_FEATURES; ++k) wd[k] = d.designer_weights[k];
 
     const int T = p.T;
+    const PkConsts pkc = pk_consts();         // constants of the packed exp (ocd_devmath.h), pinned in registers
     OCD_STAMP_DECL
     float G_ret = 0.0f;
     const BumpGeom bg0 = {0.0f, 1.0f, 0.0f, 1.0f};
@@ -474,7 +475,7 @@ mpc_kernel(const KernelParams p)
                     r = reward_state<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, true, true);
                     OCD_STAMP(5); OCD_STAMP_COUNT(12);     // every feature
                 } else if (has_f || has_col) {
-                    r = reward_one<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, nc, nf, has_col, has_f, q);
+                    r = reward_one<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, nc, nf, has_col, has_f, q, pkc);
                     OCD_STAMP(6); OCD_STAMP_COUNT(13);     // one feature per lane
                 } else {
                     r = reward_state<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, false, false);
