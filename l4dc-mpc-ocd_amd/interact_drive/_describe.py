@@ -104,14 +104,17 @@ def describe(world, car, horizon: int, learning_rate: float = 0.1, n_iter: int =
     return d
 
 
-def engine_for(desc: abi.ScenarioDesc, name: str = "custom"):
-    """One Engine per distinct descriptor (the handle owns small device-side constants)."""
+def engine_for(desc: abi.ScenarioDesc, name: str = "custom", leaf=None):
+    """One Engine per distinct descriptor (+ terminal-value table): the handle owns the device-side constants."""
     from ..engine import Engine
-    key = bytes(desc)
+    raw = bytes(desc)
+    key = raw if leaf is None else (raw, leaf.key())
     eng = _engines.get(key)
     if eng is None:
-        copy = abi.ScenarioDesc.from_buffer_copy(key)
+        copy = abi.ScenarioDesc.from_buffer_copy(raw)
         eng = Engine(Scenario(name, copy, None, None))
+        if leaf is not None:
+            eng.set_leaf_value(leaf.disc_grid, leaf.values, leaf.proj_kind)
         if len(_engines) > 64:
             _engines.clear()
         _engines[key] = eng

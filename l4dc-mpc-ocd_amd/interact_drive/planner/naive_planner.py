@@ -15,9 +15,9 @@ class NaivePlanner(CarPlanner):
     def __init__(self, world, car, horizon: int, learning_rate: float = 0.1, n_iter: int = 100,
                  leaf_evaluation=None, extra_inits=False):
         super().__init__(world, car)
-        if leaf_evaluation is not None:
-            raise NotImplementedError("leaf_evaluation (terminal value) is not compiled; every reference "
-                                      "scenario uses leaf_evaluation=None")
+        if leaf_evaluation is not None and not hasattr(leaf_evaluation, "disc_grid"):
+            raise NotImplementedError("leaf_evaluation must come from ValueFeature.interpolate_value "
+                                      "(reward_design/value_interpolation.py): arbitrary Python is not compiled")
         self.leaf_evaluation = leaf_evaluation
         self.learning_rate = learning_rate
         self.horizon = horizon
@@ -29,7 +29,7 @@ class NaivePlanner(CarPlanner):
 
     def _engine(self):
         return engine_for(describe(self.world, self.car, self.horizon, self.learning_rate, self.n_iter,
-                                   self.extra_inits))
+                                   self.extra_inits), leaf=self.leaf_evaluation)
 
     def _world_state(self, init_state):
         if init_state is None:
@@ -63,8 +63,16 @@ class NaivePlanner(CarPlanner):
         return np.stack(rows) if rows else None
 
     def reward_func(self, init_state, controls, other_controls=None, weights=None):
-        raise NotImplementedError("mpc_reward is evaluated inside the fused planner kernel; "
-                                  "use generate_plan (last_losses holds -reward of each initialisation)")
+        """mpc_reward (naive_planner.py:33-77): the predicted reward of `controls` over the horizon."""
+        return Tensor(self.reward_and_gradient(init_state, controls, other_controls, weights)[0])
+
+    def reward_and_gradient(self, init_state, controls, other_controls=None, weights=None):
+        """(R, dR/dcontrols [H, 2]): what tf.GradientTape over reward_func gives the reference's optimiser
+        (naive_planner.py:124-125,153) and its IOC code (first_order_ioc.py:86)."""
+        u = np.stack([np.asarray(c, dtype=np.float32) for c in controls]).reshape(1, self.horizon, 2)
+        out = self._engine().mpc_reward_batch(self._world_state(init_state)[None], self._weights(weights), u,
+                                              other_plans=self._other_plans(other_controls))
+        return out["reward"][0], out["grad"][0]
 
     def generate_plan(self, init_state=None, weights=None, other_controls: Optional[List] = None,
                       use_lbfgs=False) -> List[Tensor]:

@@ -283,3 +283,22 @@ def test_errors_are_reported_not_thrown(hip, eng_factory):
     h = C.c_void_p()
     assert hip.ocd_scenario_create(C.byref(bad), C.byref(h)) == abi.OCD_ERR_INVALID_ARG
     assert b"n_cars" in hip.ocd_last_error()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_finite_speed_with_overflowing_drag_bitwise(oracle, eng_factory, mode):
+    """|v| ~ 3e19 is finite but fr * v * v overflows: the LDS variant's masked fma needs a finite increment
+    (fma(-inf, 0, v) is NaN), so it must take its exact-select fallback exactly when the other variants
+    keep v; every variant has to reproduce the oracle."""
+    scn = scenarios.finite_horizon(horizon=10, n_iter=5)
+    eng = eng_factory(scn)
+    eng.set_option("scan_mode", mode)
+    ws = _world_states(scn, 9, seed=11)
+    ws[:, 0, 2] = [3e19, -3e19, 1.9e19, 1.0, 2.5e19, -1e20, 0.5, 4e19, 1e18]
+    w = np.stack([scenarios.planner_weights_fp32(c) for c in scn.candidate_weights(9, seed=12)])
+    ref = oracle.plan_batch(scn.desc, ws, w)
+    out = eng.plan_batch(ws, w, want_all=True)
+    assert_bitwise(out["all_plans"], ref["all_plans"], "plans"); assert_bitwise(out["all_losses"], ref["all_losses"], "losses")
+    rr = oracle.rollout_from_state(scn.desc, ws, w, 0, 3)
+    ro = eng.rollout_from_state(ws, w, first_step=0, n_steps=3)
+    assert_bitwise(ro["traj"], rr["traj"], "traj"); assert_bitwise(ro["returns"], rr["returns"], "returns")

@@ -131,6 +131,63 @@ def test_cmaes_minimises_a_quadratic():
     assert es.best_f < 1e-8 and np.allclose(es.mean, 0.25, atol=1e-3)
 
 
+def test_cmaes_minimises_rosenbrock_and_is_deterministic():
+    def rosen(X):
+        X = np.atleast_2d(X)
+        return np.sum(100.0 * (X[:, 1:] - X[:, :-1] ** 2) ** 2 + (1 - X[:, :-1]) ** 2, axis=1)
+
+    def run(seed, gens=600):
+        es = CMAES([-1.0, 1.5, 0.5, -0.5], 0.5, seed=seed)
+        trace = []
+        for _ in range(gens):
+            X = es.ask()
+            es.tell(X, rosen(X))
+            trace.append(es.best_f)
+            if es.stop(last_fitness=rosen(X)):
+                break
+        return es, trace
+
+    es, trace = run(5)
+    assert es.best_f < 1e-10 and np.allclose(es.best_x, 1.0, atol=1e-4)
+    assert all(b <= a for a, b in zip(trace, trace[1:]))                        # best-so-far never gets worse
+    es2, trace2 = run(5)
+    assert trace == trace2 and np.array_equal(es.mean, es2.mean)                # same seed, same run
+    es3, trace3 = run(6)
+    assert trace3 != trace                                                       # another seed, another sample path
+    # ask() hands back lambda rows and tell() counts them
+    es4 = CMAES([0.0] * 7, 0.1, popsize=16, seed=1)
+    X = es4.ask()
+    assert X.shape == (16, 7)
+    es4.tell(X, np.arange(16.0))
+    assert es4.counteval == 16 and es4.gen == 1
+
+
+def test_describe_sets_the_planner_assumptions_like_planner_car():
+    """planner_car.py:66-75: beyond its plan a FixedPlanCar is assumed to use its default_control, a
+    FixedControlCar (no .plan attribute) is assumed to do (0, 0) whatever its real control is; the teleport
+    cycle of ReplanningCarWorld has period 2 and starts with the car the next reset() removes."""
+    from l4dc_mpc_ocd_amd.interact_drive.car import FixedControlCar, FixedPlanCar
+    car, world, _ = replanning_world.setup_world(env_seeds=[1])
+    d = describe(world, car, 6)
+    assert d.teleport_period == 2 and d.teleport_step == 4
+    first = 3 - world.unlucky_car_idx
+    assert list(d.teleport_car[:2]) == [first, 3 - first]
+    assert [tuple(d.other_assumed_default[j][:]) for j in range(2)] == [tuple(d.other_default[j][:]) for j in range(2)]
+    world = ThreeLaneCarWorld()
+    ego = merging.ThreeLaneTestCar(world, np.array([0., 0., 1., np.pi / 2]), horizon=5, weights=np.ones(7), check_plans=True)
+    fc = FixedControlCar(world, np.array([0.1, -0.5, 0.5, np.pi / 2]), (0.3, -0.2))
+    fp = FixedPlanCar(world, np.array([-0.1, -0.5, 0.5, np.pi / 2]), plan=[(0.1, 0.0), (0.2, 0.1)], default_control=(0.4, 0.0))
+    world.add_cars([ego, fc, fp])
+    d = describe(world, ego, 5)
+    assert tuple(np.float32(v) for v in d.other_default[0][:]) == (np.float32(0.3), np.float32(-0.2))    # real control
+    assert tuple(d.other_assumed_default[0][:]) == (0.0, 0.0)                                             # assumed by the planner
+    assert tuple(np.float32(v) for v in d.other_assumed_default[1][:]) == (np.float32(0.4), np.float32(0.0))
+    op = scenarios.Scenario("x", d, None, None).other_plans()
+    np.testing.assert_allclose(op[0], np.zeros((5, 2)))
+    np.testing.assert_allclose(op[1][:, 0], [0.1, 0.2, 0.4, 0.4, 0.4], rtol=1e-6)
+    assert np.array_equal(op[1], fp.script_row(5)) and ego.assumed_other_controls()[1].shape == (5, 2)
+
+
 def test_history_pickle_loads_in_the_reference(tmp_path):
     """bar_plot.py:105-130 unpickles interact_drive.reward_design.mpc_ord.list2: the pickle must name that
     path, and load in a process that only has the reference's module tree (simulated by a stub)."""

@@ -36,6 +36,54 @@ def summarize(path):
     print()
 
 
+def counters_json(round_name, out_dir):
+    """profiles/pmc_counters.json: per config, the per-launch averages of the planner kernel's counters."""
+    import glob
+    import json
+    import os
+    import re
+    rec = {"_source": f"profiles/{round_name}_cfg<N>_rocprofv3.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* "
+                      "(separate passes, --kernel-trace only) of `bench.py --config N --no-extras`, kernel ocd::mpc_kernel; "
+                      "FETCH/WRITE in KiB per launch as counted (dword-granular accesses), SQ_* per launch (quad-cycles)"}
+    for d in sorted(glob.glob(os.path.join(out_dir, "c*_sq"))):
+        cfg = int(re.search(r"c(\d+)_sq", d).group(1))
+        vals = {}
+        for kind in ("fetch", "write", "sq", "stats"):
+            for path in glob.glob(os.path.join(out_dir, f"c{cfg}_{kind}", "**", "*.db"), recursive=True):
+                cur = sqlite3.connect(path).cursor()
+                try:
+                    for name, cnt, avg, grid, wg in cur.execute(
+                            "select counter_name, count(*), avg(value), max(grid_size), max(workgroup_size) "
+                            "from counters_collection where kernel_name like '%mpc_kernel%' group by counter_name"):
+                        vals[name] = avg
+                        vals["grid_size"], vals["workgroup_size"] = grid, wg
+                except sqlite3.Error:
+                    pass
+                if kind == "stats":
+                    try:
+                        for name, calls, avg in cur.execute("select name, total_calls, average from top_kernels where name like '%mpc_kernel%'"):
+                            vals["kernel_avg_us"], vals["kernel_calls"], vals["kernel_name"] = avg, calls, name
+                    except sqlite3.Error:
+                        pass
+        log = os.path.join(out_dir, f"c{cfg}_stats.log")
+        eps = None
+        if os.path.exists(log):
+            m = re.search(r'"episodes_per_gpu": (\d+)', open(log).read())
+            eps = int(m.group(1)) if m else None
+        rec[f"cfg{cfg}"] = {
+            "episodes_per_launch": eps, "fetch_kib": vals.get("FETCH_SIZE"), "write_kib": vals.get("WRITE_SIZE"),
+            "sq_waves": vals.get("SQ_WAVES"), "sq_wave_cycles": vals.get("SQ_WAVE_CYCLES"), "sq_busy_cycles": vals.get("SQ_BUSY_CYCLES"),
+            "sq_insts_valu": vals.get("SQ_INSTS_VALU"), "sq_active_inst_valu": vals.get("SQ_ACTIVE_INST_VALU"),
+            "sq_active_inst_any": vals.get("SQ_ACTIVE_INST_ANY"), "sq_wait_any": vals.get("SQ_WAIT_ANY"),
+            "sq_insts_lds": vals.get("SQ_INSTS_LDS"), "kernel_avg_us": vals.get("kernel_avg_us"),
+            "kernel_calls": vals.get("kernel_calls"), "kernel_name": vals.get("kernel_name"),
+            "grid_size": vals.get("grid_size"), "workgroup_size": vals.get("workgroup_size")}
+    print(json.dumps(rec, indent=1))
+
+
 if __name__ == "__main__":
-    for p in sys.argv[1:]:
-        summarize(p)
+    if len(sys.argv) > 1 and sys.argv[1] == "--json":
+        counters_json(sys.argv[2], sys.argv[3])
+    else:
+        for p in sys.argv[1:]:
+            summarize(p)
