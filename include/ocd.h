@@ -141,8 +141,8 @@ void ocd_scenario_destroy(ocd_scenario *scn);
  *   "scan_mode": how the horizon recurrences exchange terms and where the K control initialisations
  *                live: 0 = automatic, 1 = LDS windows (K wavefronts per workgroup), 2 = DPP row shifts
  *                (H <= 16, K wavefronts per workgroup), 3 = all K initialisations in one wavefront
- *                (K*H <= 64, wavefront shifts, no workgroup barrier); a mode the scenario cannot use
- *                falls back to 1;
+ *                (K*H <= 64, wavefront shifts, no workgroup barrier), 4 = a lane owns a chunk of consecutive
+ *                horizon steps (long horizons at throughput); a mode the scenario cannot use falls back to 1;
  *   "no_unified_features": 1 = never evaluate a lane's single active feature through the shared path;
  *   "no_feature_skips": 1 = evaluate the collision and fence features even where they are provably
  *                       zero (diagnostics; default 0).

@@ -195,7 +195,7 @@ int32_t ocd_scenario_set_option(ocd_scenario *scn, const char *name, int32_t val
         return OCD_OK;
     }
     if (std::strcmp(name, "scan_mode") == 0) {
-        if (value < 0 || value > 3) return fail(OCD_ERR_INVALID_ARG, "scan_mode %d out of [0,3]", value);
+        if (value < 0 || value > 4) return fail(OCD_ERR_INVALID_ARG, "scan_mode %d out of [0,4]", value);
         scn->opt_scan_mode = value;
         return OCD_OK;
     }

@@ -1,0 +1,485 @@
+// ocd_chunk_kernel.hip -- the planner kernel for long horizons at throughput (V_CHUNK), gfx950.
+//
+// Same algorithm, arithmetic contract and entry points as ocd::mpc_kernel (ocd_kernels.hip; reference:
+// naive_planner.py:33-77,81-164, simulation_utils.py:9-21, merging.py:32-83, mpc_ord.py:67-106); what
+// changes is the mapping.  With one lane per horizon step every lane runs all H-1 rounds of the four
+// horizon recurrences -- O(H^2) lane-work, two thirds of the kernel time at H = 25.  Here a lane owns a
+// CHUNK of S consecutive steps, NC = H/S lanes per (trajectory, control initialisation) pair:
+//
+//   * the recurrences run NC-1 rounds, each walking the lane's S steps sequentially and handing the
+//     chunk's end value to the neighbouring lane (wave_shr:1 / wave_shl:1 + a select at the segment
+//     boundary, as in V_SEG): the rounds of a wavefront cost about what they cost before, but the
+//     wavefront now holds S times as many problems (64/NC segments instead of 64/H);
+//   * the lane-parallel work of a step (sincos, reward features, Jacobian products) is done S times per
+//     lane, at full lane utilisation -- it becomes 80 % of a pass, which is what the algorithm needs.
+//
+// ONE wavefront per workgroup; segment (j, k) = trajectory j, initialisation k; the first-index argmin
+// over the K initialisations is taken inside the wavefront (ds_bpermute), no LDS, no barrier.
+// Sums keep the reference's sequential order (the chunk's partial value travels up / down the segment),
+// so results are bit-identical to the other variants and to the oracle.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ocd.h"
+#include "ocd_device.h"
+#include "ocd_kernels.h"
+#include "ocd_lane.h"
+
+namespace ocd {
+
+template <int HT, int NO, int L, int S>
+__global__ void __launch_bounds__(64)
+mpc_chunk_kernel(const KernelParams p)
+{
+    static_assert(HT % S == 0, "the chunk size divides the horizon");
+    constexpr int H = HT;
+    constexpr int NC = HT / S;                                 // lanes per (trajectory, initialisation)
+    constexpr int NOA = NO > 0 ? NO : 1;
+    constexpr bool lane_feats = L > 0;
+    constexpr int D = L > 0 ? L + 4 : 0;
+    const ocd_scenario_desc &d = p.d;
+    const int K = p.K;
+    const int lane = threadIdx.x & 63;
+    const int seg = lane / NC;
+    const int c = lane - seg * NC;                             // chunk index: steps c*S .. c*S+S-1
+    const bool first = c == 0, last = c == NC - 1;
+    const int slot = seg / K;                                  // trajectory slot inside the wavefront
+    const int kinit = seg - slot * K;
+
+    const long long prob_raw = (long long)blockIdx.x * p.segs_used + slot;
+    const bool live = (slot < p.segs_used) && (prob_raw < p.n_problems);
+    const long long prob = live ? prob_raw : (p.n_problems - 1);   // parked lanes shadow a real problem
+    const unsigned long long live_mask = __ballot(live);
+
+    const float dt = d.dt, dt2 = d.dt_sq, fr = d.ego_friction, lr = d.learning_rate;
+
+    // ---- problem inputs (as in mpc_kernel) ----
+    float ex, ey, ev, eth;
+    float ox[NOA], oy[NOA], ov[NOA], oth[NOA];
+    float w[OCD_MAX_FEATURES];
+    int tp_idx = 0;
+    if (p.mode == OCD_MODE_ROLLOUT && !p.from_state) {
+        const long long e_glob = p.ep_begin + prob;
+        const long long s_ = e_glob % p.S, n_ = (e_glob / p.S) % p.N, p_ = e_glob / ((long long)p.S * p.N);
+        tp_idx = d.teleport_period > 0 ? (int)((p.reset_phase + e_glob) % d.teleport_period) : (int)s_;
+        const float *ini = p.ego_states + 4 * n_;
+        ex = ini[0]; ey = ini[1]; ev = ini[2]; eth = ini[3];
+#pragma unroll
+        for (int j = 0; j < NO; ++j) {
+            ox[j] = d.other_init[j][0]; oy[j] = d.other_init[j][1];
+            ov[j] = d.other_init[j][2]; oth[j] = d.other_init[j][3];
+        }
+#pragma unroll
+        for (int k = 0; k < OCD_MAX_FEATURES; ++k) w[k] = (p.weights && k < D) ? p.weights[p_ * D + k] : 0.0f;
+    } else {
+        const float *ws = p.ego_states + prob * (NO + 1) * 4;
+        ex = ws[0]; ey = ws[1]; ev = ws[2]; eth = ws[3];
+#pragma unroll
+        for (int j = 0; j < NO; ++j) {
+            ox[j] = ws[4 * (j + 1)]; oy[j] = ws[4 * (j + 1) + 1];
+            ov[j] = ws[4 * (j + 1) + 2]; oth[j] = ws[4 * (j + 1) + 3];
+        }
+        const float *wp = p.weights ? (p.weights + (p.weights_per_problem ? prob * D : 0)) : nullptr;
+#pragma unroll
+        for (int k = 0; k < OCD_MAX_FEATURES; ++k) w[k] = (wp && k < D) ? wp[k] : 0.0f;
+        tp_idx = p.sample_fixed;
+    }
+    float wd[OCD_MAX_FEATURES];
+#pragma unroll
+    for (int k = 0; k < OCD_MAX_FEATURES; ++k) wd[k] = d.designer_weights[k];
+
+    const int T = p.T;
+    const PkConsts pkc = pk_consts();
+    float G_ret = 0.0f;
+    const BumpGeom bg0 = {0.0f, 1.0f, 0.0f, 1.0f};
+    const bool writer = live && kinit == 0 && first;
+
+    if (p.mode == OCD_MODE_ROLLOUT && p.traj_out && writer) {
+        float *tr = p.traj_out + (size_t)prob * (T + 1) * (NO + 1) * 4;
+        tr[0] = ex; tr[1] = ey; tr[2] = ev; tr[3] = eth;
+#pragma unroll
+        for (int j = 0; j < NO; ++j) {
+            tr[4 * (j + 1)] = ox[j]; tr[4 * (j + 1) + 1] = oy[j]; tr[4 * (j + 1) + 2] = ov[j]; tr[4 * (j + 1) + 3] = oth[j];
+        }
+    }
+
+    for (int step = 0; step < T; ++step) {
+        if (p.mode == OCD_MODE_ROLLOUT) {
+            if (d.teleport_step > 0 && (p.t0 + step + 1) == d.teleport_step) {
+                const int car = d.teleport_car[tp_idx & (OCD_MAX_SAMPLES - 1)];
+#pragma unroll
+                for (int j = 0; j < NO; ++j) {
+                    if (car == j + 1) {
+                        ox[j] = d.teleport_state[0]; oy[j] = d.teleport_state[1];
+                        ov[j] = d.teleport_state[2]; oth[j] = d.teleport_state[3];
+                    }
+                }
+            }
+            BumpGeom bgd[NOA];
+            bgd[0] = bg0;
+#pragma unroll
+            for (int j = 0; j < NO; ++j) bgd[j] = bump_geom(ox[j], oy[j], d.bump_half_x, d.bump_half_y);
+            float s_, c_;
+            sincos_(eth, s_, c_);
+            Q4 qd;
+            const float r = reward_state<NO, L, false>(d, wd, ex, ey, ev, s_, c_, bgd, qd, nullptr);
+            G_ret = G_ret + r;
+        }
+
+        // ---- planner's model of the scripted cars at this lane's S steps (naive_planner.py:51-66) ----
+        BumpGeom bg[S][NOA];
+        float wx1[S][NOA], wy1[S][NOA];
+#pragma unroll
+        for (int s = 0; s < S; ++s) bg[s][0] = bg0;
+#pragma unroll
+        for (int j = 0; j < NO; ++j) {
+            float px = ox[j], py = oy[j], pv = ov[j], pth = oth[j];
+            float cap_x[S], cap_y[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) { cap_x[s] = px; cap_y[s] = py; }
+            if (p.other_plans) {
+                for (int tt = 0; tt < H; ++tt) {
+                    float s_, c_;
+                    sincos_(pth, s_, c_);
+                    const float acc = p.other_plans[(j * H + tt) * 2], angv = p.other_plans[(j * H + tt) * 2 + 1];
+                    const float dist = pv * dt + (0.5f * acc) * dt2;
+                    px = px + c_ * dist;
+                    py = py + s_ * dist;
+                    pv = pv + acc * dt;
+                    pth = pth + angv * dt;
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        cap_x[s] = (tt == c * S + s) ? px : cap_x[s];
+                        cap_y[s] = (tt == c * S + s) ? py : cap_y[s];
+                    }
+                }
+            } else {
+                float s_, c_;
+                sincos_(pth, s_, c_);
+                const float incx = (c_ * pv) * dt, incy = (s_ * pv) * dt;
+                for (int tt = 0; tt < H; ++tt) {
+                    px = px + incx;
+                    py = py + incy;
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        cap_x[s] = (tt == c * S + s) ? px : cap_x[s];
+                        cap_y[s] = (tt == c * S + s) ? py : cap_y[s];
+                    }
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < S; ++s) bg[s][j] = bump_geom(cap_x[s], cap_y[s], d.bump_half_x, d.bump_half_y);
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int j = 0; j < NOA; ++j) { wx1[s][j] = bg[s][j].wx * 1.001f; wy1[s][j] = bg[s][j].wy * 1.001f; }
+
+        // ---- control initialisation of this segment (naive_planner.py:107-116) ----
+        float s0, c0;
+        sincos_(eth, s0, c0);
+        const float a_coast = fr * (ev * ev);
+        const int k3 = kinit % 3;
+        float ua[S], uw[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            ua[s] = (kinit >= 3) ? a_coast : 0.0f;
+            uw[s] = (k3 == 0) ? 0.0f : ((k3 == 1) ? -0.65f : 0.65f);
+        }
+        float loss = 0.0f;
+
+        auto horizon_pass = [&](auto grad_tag) __attribute__((always_inline)) {
+            constexpr bool GRAD = decltype(grad_tag)::value;
+            // ===== forward =====
+            float a_c[S], wdt[S];
+            bool pass_a[S], pass_w[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const float a1 = min_tf(ua[s], 4.0f);
+                a_c[s] = max_tf(a1, -8.0f);
+                const float w1 = min_tf(uw[s], 4.0f);
+                const float w_c = max_tf(w1, -4.0f);
+                pass_a[s] = (ua[s] <= 4.0f) && (a1 >= -8.0f);
+                pass_w[s] = (uw[s] <= 4.0f) && (w1 >= -4.0f);
+                wdt[s] = w_c * dt;
+            }
+            // speed / heading at the start of the chunk: NC-1 rounds of "walk my S steps, hand the end to the lane above"
+            float vs = ev, ths = eth;
+#pragma unroll
+            for (int r = 0; r < NC - 1; ++r) {
+                float v = vs, th = ths;
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    v = v + (a_c[s] - fr * (v * v)) * dt;
+                    th = th + wdt[s];
+                }
+                const float vb = wave_below(v), tb = wave_below(th);
+                vs = first ? ev : vb;
+                ths = first ? eth : tb;
+            }
+            // the lane's own S steps
+            float vpre[S], dd[S], vn[S], sn[S], cn[S];
+            {
+                float v = vs, th = ths;
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const float v2 = v * v;
+                    const float fv2 = fr * v2;
+                    const float acc = a_c[s] - fv2;
+                    const float vdt = v * dt;
+                    const float hA = 0.5f * acc;
+                    const float hAdt2 = hA * dt2;
+                    vpre[s] = v;
+                    dd[s] = vdt + hAdt2;
+                    v = v + acc * dt;
+                    th = th + wdt[s];
+                    vn[s] = v;
+                    sincos_(th, sn[s], cn[s]);
+                }
+            }
+            // sin / cos of the heading BEFORE each step: the previous step's, across the lane boundary for s = 0
+            float s_pre[S], c_pre[S];
+            {
+                const float sb = wave_below(sn[S - 1]), cb = wave_below(cn[S - 1]);
+                s_pre[0] = first ? s0 : sb;
+                c_pre[0] = first ? c0 : cb;
+#pragma unroll
+                for (int s = 1; s < S; ++s) { s_pre[s] = sn[s - 1]; c_pre[s] = cn[s - 1]; }
+            }
+            float cd[S], sd[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) { cd[s] = c_pre[s] * dd[s]; sd[s] = s_pre[s] * dd[s]; }
+            // position at the start of the chunk
+            float xs = ex, ys = ey;
+#pragma unroll
+            for (int r = 0; r < NC - 1; ++r) {
+                float x = xs, y = ys;
+#pragma unroll
+                for (int s = 0; s < S; ++s) { x = x + cd[s]; y = y + sd[s]; }
+                const float xb = wave_below(x), yb = wave_below(y);
+                xs = first ? ex : xb;
+                ys = first ? ey : yb;
+            }
+
+            // ===== reward features at the S post-step states =====
+            Q4 q[S];
+            float rw[S];
+            {
+                float x = xs, y = ys;
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    x = x + cd[s];
+                    y = y + sd[s];
+                    const float xn = x, yn = y;
+                    if constexpr (lane_feats) {
+                        bool nc[NOA];
+                        nc[0] = false;
+                        const bool nf = needs_fence(d, xn);
+                        unsigned long long mf = __ballot(nf) & live_mask, mc_any = 0ull, multi = 0ull;
+#pragma unroll
+                        for (int j = 0; j < NO; ++j) {
+                            const float dx = xn - bg[s][j].cx, dy = yn - bg[s][j].cy;
+                            nc[j] = (__builtin_fabsf(dx) < wx1[s][j]) && (__builtin_fabsf(dy) < wy1[s][j]);
+                            const unsigned long long mj = __ballot(nc[j]) & live_mask;
+                            multi |= (mj & (mf | mc_any));
+                            mc_any |= mj;
+                        }
+                        const bool has_f = mf != 0ull, has_col = mc_any != 0ull;
+                        if (p.no_skips || multi != 0ull || (p.no_unify && (has_f || has_col))) {
+                            rw[s] = reward_state<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], q[s], nullptr, true, true);
+                        } else if (has_f || has_col) {
+                            rw[s] = reward_one<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], nc, nf, has_col, has_f, q[s], pkc);
+                        } else {
+                            rw[s] = reward_state<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], q[s], nullptr, false, false);
+                        }
+                    } else {
+                        rw[s] = reward_state<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], q[s], nullptr);
+                    }
+                }
+            }
+
+            if constexpr (!GRAD) {
+                // ===== objective only: r = 0; r += reward, t = 0..H-1, in that order =====
+                float Rs = 0.0f;                               // partial sum at the start of the chunk
+                float R = 0.0f;
+#pragma unroll
+                for (int r = 0; r < NC; ++r) {
+                    R = Rs;
+#pragma unroll
+                    for (int s = 0; s < S; ++s) R = R + rw[s];
+                    if (r < NC - 1) {
+                        const float Rb = wave_below(R);
+                        Rs = first ? 0.0f : Rb;
+                    }
+                }
+                loss = -R;                                     // complete in the segment's last lane
+            } else {
+                // ===== backward =====
+                // position adjoint arriving at the END of the chunk (from the later chunks)
+                float LxE = 0.0f, LyE = 0.0f;
+#pragma unroll
+                for (int r = 0; r < NC - 1; ++r) {
+                    float Lx = LxE, Ly = LyE;
+#pragma unroll
+                    for (int s = S - 1; s >= 0; --s) { Lx = q[s].qx + Lx; Ly = q[s].qy + Ly; }
+                    const float xa = wave_above(Lx), ya = wave_above(Ly);
+                    LxE = last ? 0.0f : xa;
+                    LyE = last ? 0.0f : ya;
+                }
+                float tau[S], gv1[S], gA1[S];
+                {
+                    float Lx = LxE, Ly = LyE;
+#pragma unroll
+                    for (int s = S - 1; s >= 0; --s) {
+                        const float Ax = q[s].qx + Lx;
+                        const float Ay = q[s].qy + Ly;
+                        const float g_c = Ax * dd[s];
+                        const float g_s = Ay * dd[s];
+                        const float g_d = Ax * c_pre[s] + Ay * s_pre[s];
+                        tau[s] = (-g_c) * s_pre[s] + g_s * c_pre[s];
+                        gv1[s] = g_d * dt;
+                        gA1[s] = (g_d * dt2) * 0.5f;
+                        Lx = Ax; Ly = Ay;
+                    }
+                }
+                // speed / heading adjoint arriving at the end of the chunk
+                float LvE = 0.0f, LthE = 0.0f;
+#pragma unroll
+                for (int r = 0; r < NC - 1; ++r) {
+                    float Lv = LvE, Lth = LthE;
+#pragma unroll
+                    for (int s = S - 1; s >= 0; --s) {
+                        const float Av_ = q[s].qv + Lv;
+                        const float gA_ = gA1[s] + Av_ * dt;
+                        const float gv2_ = (-gA_) * fr;
+                        const float gv3_ = (gv2_ * 2.0f) * vpre[s];
+                        Lv = (gv1[s] + Av_) + gv3_;
+                        Lth = (q[s].qth + Lth) + tau[s];
+                    }
+                    const float va = wave_above(Lv), ta = wave_above(Lth);
+                    LvE = last ? 0.0f : va;
+                    LthE = last ? 0.0f : ta;
+                }
+                {
+                    float Lv = LvE, Lth = LthE;
+#pragma unroll
+                    for (int s = S - 1; s >= 0; --s) {
+                        const float Av = q[s].qv + Lv;
+                        const float gA = gA1[s] + Av * dt;
+                        const float Ath = q[s].qth + Lth;
+                        const float grad_a = pass_a[s] ? gA : 0.0f;
+                        const float grad_w = pass_w[s] ? (Ath * dt) : 0.0f;
+                        const float gv2_ = (-gA) * fr;
+                        const float gv3_ = (gv2_ * 2.0f) * vpre[s];
+                        Lv = (gv1[s] + Av) + gv3_;
+                        Lth = Ath + tau[s];
+                        // SGD on loss = -R:  u <- u + lr * dR/du
+                        ua[s] = ua[s] + lr * grad_a;
+                        uw[s] = uw[s] + lr * grad_w;
+                    }
+                }
+            }
+        };
+
+        const int n_iter = d.n_iter;
+        for (int it = 0; it < n_iter; ++it) horizon_pass(bool_c<true>{});
+        horizon_pass(bool_c<false>{});
+
+        // ---- per-initialisation outputs (plan mode, parity tests) ----
+        if (p.mode == OCD_MODE_PLAN && live) {
+            if (p.all_plans_out) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    float *o = p.all_plans_out + (((size_t)prob * K + kinit) * H + (c * S + s)) * 2;
+                    o[0] = ua[s]; o[1] = uw[s];
+                }
+            }
+            if (p.all_losses_out && last) p.all_losses_out[(size_t)prob * K + kinit] = loss;
+        }
+
+        // ---- first-index argmin over the K initialisations (naive_planner.py:161-162) ----
+        int best = 0;
+        const int base = slot * K * NC;                          // first lane of this trajectory's K segments
+        float bl = lane_read(loss, base + NC - 1);
+        for (int k = 1; k < K; ++k) {
+            const float lk = lane_read(loss, base + k * NC + NC - 1);
+            if (lk < bl) { bl = lk; best = k; }
+        }
+        const float ca = lane_read(ua[0], base + best * NC);
+        const float cw = lane_read(uw[0], base + best * NC);
+
+        if (p.mode == OCD_MODE_PLAN) {
+            if (live && kinit == best) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    float *o = p.plans_out + ((size_t)prob * H + (c * S + s)) * 2;
+                    o[0] = ua[s]; o[1] = uw[s];
+                }
+                if (first) {
+                    if (p.best_loss_out) p.best_loss_out[prob] = bl;
+                    if (p.best_init_out) p.best_init_out[prob] = best;
+                }
+            }
+        } else {
+            // ---- every car steps through the real dynamics (world.py:106-107) ----
+            float nx, ny, nv, nth;
+            dyn_step(ex, ey, ev, eth, c0, s0, ca, cw, dt, dt2, fr, nx, ny, nv, nth);
+            ex = nx; ey = ny; ev = nv; eth = nth;
+#pragma unroll
+            for (int j = 0; j < NO; ++j) {
+                const int gstep = p.t0 + step;
+                const bool in_plan = gstep < d.other_plan_len[j];
+                const float u0 = in_plan ? d.other_plan[j][gstep & (OCD_MAX_PLAN - 1)][0] : d.other_default[j][0];
+                const float u1 = in_plan ? d.other_plan[j][gstep & (OCD_MAX_PLAN - 1)][1] : d.other_default[j][1];
+                float s_, c_;
+                sincos_(oth[j], s_, c_);
+                dyn_step(ox[j], oy[j], ov[j], oth[j], c_, s_, u0, u1, dt, dt2, d.other_friction[j], nx, ny, nv, nth);
+                ox[j] = nx; oy[j] = ny; ov[j] = nv; oth[j] = nth;
+            }
+            if (writer) {
+                if (p.ctrl_out) {
+                    float *o = p.ctrl_out + ((size_t)prob * T + step) * 2;
+                    o[0] = ca; o[1] = cw;
+                }
+                if (p.traj_out) {
+                    float *tr = p.traj_out + ((size_t)prob * (T + 1) + step + 1) * (NO + 1) * 4;
+                    tr[0] = ex; tr[1] = ey; tr[2] = ev; tr[3] = eth;
+#pragma unroll
+                    for (int j = 0; j < NO; ++j) {
+                        tr[4 * (j + 1)] = ox[j]; tr[4 * (j + 1) + 1] = oy[j];
+                        tr[4 * (j + 1) + 2] = ov[j]; tr[4 * (j + 1) + 3] = oth[j];
+                    }
+                }
+            }
+        }
+    }
+    if (p.mode == OCD_MODE_ROLLOUT && writer) p.returns_out[prob] = G_ret;
+}
+
+// ---------------------------------------------------------------- launch
+template <int HT, int NO, int L, int S>
+static hipError_t launch_chunk(const KernelParams &p_in, hipStream_t st)
+{
+    KernelParams p = p_in;
+    constexpr int NC = HT / S;
+    const int cap = 64 / (p.K * NC);                            // trajectories per wavefront
+    if (cap < 1) return hipErrorInvalidConfiguration;
+    int segs = p.segs_used > 0 ? p.segs_used : cap;
+    segs = segs < 1 ? 1 : (segs > cap ? cap : segs);
+    p.segs_used = segs;
+    const unsigned blocks = (unsigned)((p.n_problems + segs - 1) / segs);
+    hipLaunchKernelGGL((mpc_chunk_kernel<HT, NO, L, S>), dim3(blocks), dim3(64), 0, st, p);
+    return hipGetLastError();
+}
+
+#define OCD_CCASE(HH, NN, LL, SS) if (H == HH && NO == NN && L == LL) { *chunk = SS; if (launch) return launch_chunk<HH, NN, LL, SS>(p, st); return hipSuccess; }
+
+// chunk = 0 and hipSuccess: no chunked kernel for this shape.  launch = false only asks.
+hipError_t launch_chunk_dispatch(int H, int NO, int L, const KernelParams &p, hipStream_t st, bool launch, int *chunk)
+{
+    *chunk = 0;
+    OCD_CHUNK_TABLE(OCD_CCASE)
+    return hipSuccess;
+}
+
+} // namespace ocd

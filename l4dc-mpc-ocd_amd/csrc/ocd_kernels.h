@@ -14,8 +14,10 @@ enum {
     V_LDS = 0,   // K wavefronts per workgroup (one per control initialisation), segments of H lanes,
                  // zero-padded LDS windows: any H, the throughput variant
     V_ROW = 1,   // K wavefronts per workgroup, one trajectory per 16-lane DPP row (H <= 16): row_shr/row_shl
-    V_SEG = 2    // ONE wavefront per workgroup holding all K initialisations of its trajectories in
+    V_SEG = 2,   // ONE wavefront per workgroup holding all K initialisations of its trajectories in
                  // segments of H lanes (K*H <= 64): wave_shr/wave_shl moves, argmin inside the wavefront
+    V_CHUNK = 3  // ONE wavefront per workgroup, a lane owns a chunk of S consecutive horizon steps, H/S lanes
+                 // per (trajectory, initialisation): long horizons at throughput (ocd_chunk_kernel.hip)
 };
 
 // Terminal-value table of the planner (leaf_evaluation); device pointers owned by the scenario handle
@@ -56,7 +58,7 @@ struct KernelParams {
     int32_t reset_phase;       // ROLLOUT: world.reset() calls before episode 0 of this batch (teleport cycle)
     int32_t segs_used;         // trajectories per wavefront; 0 = let the launcher choose
     int32_t no_skips;          // diagnostics: 1 = always evaluate collision and fence features
-    int32_t scan_mode;         // 0 = automatic, 1 = V_LDS, 2 = V_ROW, 3 = V_SEG
+    int32_t scan_mode;         // 0 = automatic, 1 = V_LDS, 2 = V_ROW, 3 = V_SEG, 4 = V_CHUNK
     int32_t no_unify;          // diagnostics: 1 = never use the one-feature-per-lane evaluation
     int32_t n_cus;             // compute units of the device (launch shape heuristics)
     unsigned long long *debug; // diagnostic builds only (OCD_STAMPS): per-wavefront cycle totals, else nullptr
@@ -80,7 +82,15 @@ struct KernelParams {
     X(2, 1) X(2, 2) X(2, 3) X(2, 4)                                                           \
     X(3, 1) X(3, 2) X(3, 3) X(3, 4)
 
+// (horizon H, scripted cars NO, lanes L, chunk S) with a chunked kernel (V_CHUNK)
+#define OCD_CHUNK_TABLE(X)                                                                    \
+    X(10, 1, 3, 5) X(15, 1, 3, 5) X(25, 1, 3, 5)                                              \
+    X(10, 2, 2, 5) X(15, 2, 2, 5)                                                             \
+    X(10, 2, 3, 5) X(25, 2, 3, 5)
+
 hipError_t launch_mpc_dispatch(int H, int NO, int L, const KernelParams &p, hipStream_t st, bool *supported);
+// V_CHUNK: *chunk = the chunk size compiled for this shape (0 = none); launches when `launch`
+hipError_t launch_chunk_dispatch(int H, int NO, int L, const KernelParams &p, hipStream_t st, bool launch, int *chunk);
 hipError_t launch_reward(int NO, int L, const KernelParams &p, float *feats, float *rew, hipStream_t st, bool *supported);
 // R(u) and dR/du for caller-supplied controls [B,H,2] (naive_planner.py:33-77)
 hipError_t launch_objective(int NO, int L, const KernelParams &p, const float *controls, float *reward_out,

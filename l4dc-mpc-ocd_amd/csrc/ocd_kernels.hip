@@ -39,6 +39,7 @@
 
 #include "../../include/ocd.h"
 #include "ocd_chains.h"
+#include "ocd_lane.h"
 #include "ocd_device.h"
 #include "ocd_kernels.h"
 
@@ -83,49 +84,6 @@ __host__ __device__ constexpr Geo geo_lds(int H)
     g.SEL_FLOATS = g.ROWS * 4;
     return g;
 }
-
-__device__ __forceinline__ bool finite_(float v)
-{
-    return (__float_as_uint(v) & 0x7f800000u) != 0x7f800000u;
-}
-
-// DPP moves.  row_shr:1 / row_shl:1 stay inside a 16-lane row (the first / last lane of the row has no
-// source); wave_shr:1 / wave_shl:1 shift across the whole wavefront.  BC = bound_ctrl: a lane without a
-// source reads 0; otherwise it keeps `old`.
-constexpr int DPP_ROW_SHL1 = 0x101, DPP_ROW_SHR1 = 0x111, DPP_WAVE_SHL1 = 0x130, DPP_WAVE_SHR1 = 0x138;
-
-template <int CTRL, bool BC>
-__device__ __forceinline__ float dpp_move(float old, float src)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, 0xf, 0xf, BC));
-}
-
-// V_ROW: lane t of a row receives lane t-1 / t+1; the boundary lane keeps `old`
-__device__ __forceinline__ float row_below(float old, float src) { return dpp_move<DPP_ROW_SHR1, false>(old, src); }
-__device__ __forceinline__ float row_above(float old, float src) { return dpp_move<DPP_ROW_SHL1, false>(old, src); }
-// V_SEG: lane l receives lane l-1 / l+1 of the wavefront; the caller selects at segment boundaries
-__device__ __forceinline__ float wave_below(float src) { return dpp_move<DPP_WAVE_SHR1, true>(0.0f, src); }
-__device__ __forceinline__ float wave_above(float src) { return dpp_move<DPP_WAVE_SHL1, true>(0.0f, src); }
-
-__device__ __forceinline__ float lane_read(float v, int src_lane)
-{
-    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
-}
-
-template <bool B> using bool_c = std::integral_constant<bool, B>;
-
-// In-kernel cycle stamps (diagnostic build only: make STAMPS=1; never shipped).  Section totals of
-// wavefront (block, wave) go to p.debug[(block * K + wave) * 16 + section]; no output depends on them.
-#ifdef OCD_STAMPS
-#define OCD_STAMP_DECL unsigned long long st_acc[16] = {0}, st_last = __builtin_amdgcn_s_memtime();
-#define OCD_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long st_now = __builtin_amdgcn_s_memtime(); \
-                          __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); st_acc[i] += st_now - st_last; st_last = st_now; } while (0)
-#define OCD_STAMP_COUNT(i) do { st_acc[i] += 1; } while (0)
-#else
-#define OCD_STAMP_DECL
-#define OCD_STAMP(i) do { } while (0)
-#define OCD_STAMP_COUNT(i) do { } while (0)
-#endif
 
 // ---------------------------------------------------------------- the kernel
 // LEAF: the terminal-value lookup (leaf_evaluation) is compiled into the generic kernel only.
@@ -890,15 +848,16 @@ namespace ocd {
 static long long ceil_div(long long a, long long b) { return (a + b - 1) / b; }
 static int clampi(long long v, long long lo, long long hi) { return (int)(v < lo ? lo : (v > hi ? hi : v)); }
 
-// Variant and packing.  What decides the kernel time of a small or medium batch
-// is how many wavefronts the busiest SIMD gets, and a wavefront's own instruction stream:
-//   * up to one trajectory-initialisation per SIMD: V_ROW, one trajectory per wavefront (every
-//     initialisation decides its feature skips alone; K wavefronts meet once per control step);
-//   * up to about one V_SEG wavefront per SIMD (64/(K*H) trajectories each): V_SEG -- single-wavefront
-//     workgroups spread evenly over the SIMDs, no workgroup barrier;
-//   * beyond: V_LDS, densest packing (64/H trajectories per wavefront), LDS latency hidden by the other
-//     wavefronts of the SIMD.
-// scan_mode 1 / 2 / 3 and segs_per_wave force the choice (tests, sweeps).
+// Variant and packing, from measurements on MI355X (tools/sweep.py).  What decides
+// the kernel time is how many wavefronts the busiest SIMD gets and a wavefront's own instruction stream:
+//   * trajectories x K <= SIMDs: V_ROW, one trajectory per wavefront (every initialisation decides its
+//     feature skips alone; K wavefronts meet once per control step);
+//   * V_SEG (single-wavefront workgroups spread evenly over the SIMDs, no workgroup barrier) while it gives
+//     at most one wavefront per SIMD, or up to four when it packs lanes as densely as V_LDS (K*H close to 64);
+//   * V_CHUNK once its wavefronts (S times the problems each) fill enough of the chip: from 3/4 of the SIMDs
+//     at H >= 20, where the O(H^2) recurrence work it removes dominates, later for shorter horizons;
+//   * else V_LDS, densest packing at one lane per step, LDS latency hidden by the other wavefronts.
+// scan_mode 1..4 and segs_per_wave force the choice (tests, sweeps).
 template <int HT, int NO, int L>
 static hipError_t launch_mpc(const KernelParams &p_in, hipStream_t st)
 {
@@ -910,15 +869,25 @@ static hipError_t launch_mpc(const KernelParams &p_in, hipStream_t st)
     const long long n = p.n_problems;
     const int seg_cap = (HT > 0 && K * H <= 64) ? 64 / (K * H) : 0;    // V_SEG trajectories per wavefront
     const int row_cap = (HT > 0 && H <= 16) ? 4 : 0;                   // V_ROW
+    int chunk = 0;                                                     // V_CHUNK: chunk size compiled for this shape
+    (void)launch_chunk_dispatch(H, NO, L, p, st, false, &chunk);
+    if (chunk && 64 / (K * (H / chunk)) < 1) chunk = 0;
     int variant = V_LDS;
     if (p.leaf.values) variant = V_LDS;                                // the terminal value lives in the generic kernel
+    else if (p.scan_mode == 4 && chunk) variant = V_CHUNK;
     else if (p.scan_mode == 2 && row_cap) variant = V_ROW;
     else if (p.scan_mode == 3 && seg_cap) variant = V_SEG;
     else if (p.scan_mode == 0) {
+        const long long waves_seg = seg_cap ? ceil_div(n, seg_cap) : 0;
+        const long long waves_lds = ceil_div(n, G.SEGS) * K;
+        const long long waves_chunk = chunk ? ceil_div(n, 64 / (K * (H / chunk))) : 0;
+        const long long chunk_from = (H >= 20) ? (3 * simds) / 4 : ((H >= 15) ? 2 * simds : 3 * simds);
         if (row_cap && n * K <= simds) variant = V_ROW;
-        else if (seg_cap && ceil_div(n, seg_cap) <= 2 * simds) variant = V_SEG;
+        else if (seg_cap && (waves_seg <= simds || (waves_seg * 20 <= waves_lds * 21 && waves_seg <= 4 * simds))) variant = V_SEG;
+        else if (chunk && waves_chunk >= chunk_from) variant = V_CHUNK;
         else if (row_cap && ceil_div(n, row_cap) * K <= simds) variant = V_ROW;
     }
+    if (variant == V_CHUNK) return launch_chunk_dispatch(H, NO, L, p, st, true, &chunk);
     int segs;
     if (variant == V_ROW) segs = p.segs_used > 0 ? clampi(p.segs_used, 1, row_cap) : clampi(ceil_div(n * K, simds), 1, row_cap);
     else if (variant == V_SEG) segs = p.segs_used > 0 ? clampi(p.segs_used, 1, seg_cap) : clampi(ceil_div(n, simds), 1, seg_cap);

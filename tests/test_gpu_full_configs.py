@@ -27,7 +27,7 @@ def _engine(scn):
     return Engine(scn, "cuda:0")
 
 
-@pytest.mark.parametrize("scan_mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("scan_mode", [0, 1, 2, 3, 4])
 def test_config3_every_episode_bitwise(hip, oracle, scan_mode):
     scn, inits, w32 = _inputs(3)
     ref = oracle.rollout(scn.desc, inits, w32, n_threads=THREADS)["returns"]
@@ -64,7 +64,8 @@ def test_configs_4_5_full_size(hip, oracle, cfg, n_sampled_ranges):
     assert np.array_equal(permuted, full.reshape(P, N * S)[perm])
     # every other launch shape on EVERY episode: one trajectory per wavefront, (H <= 16) the DPP-row variant,
     # (K*H <= 64) all initialisations in one wavefront
-    shapes = [(1, 1)] + ([(2, 0), (2, 1)] if scn.desc.horizon <= 16 else []) + ([(3, 0)] if 3 * scn.desc.horizon <= 64 else [])
+    shapes = [(1, 1), (1, 0), (4, 0), (4, 2)] + ([(2, 0), (2, 1)] if scn.desc.horizon <= 16 else []) + \
+             ([(3, 0)] if 3 * scn.desc.horizon <= 64 else [])
     for mode, segs in shapes:
         eng.set_option("scan_mode", mode); eng.set_option("segs_per_wave", segs)
         try:

@@ -155,14 +155,15 @@ def test_rollout_bitwise(oracle, eng_factory, name, H, P, N):
     assert out["returns"].shape == (P * N * scn.desc.n_samples,)
 
 
-@pytest.mark.parametrize("scan_mode", [1, 2, 3])
+@pytest.mark.parametrize("scan_mode", [1, 2, 3, 4])
 @pytest.mark.parametrize("name,H,n_iter", [("finite_horizon", 10, 40), ("replanning", 15, 25), ("merging", 5, 40),
-                                           ("local_opt", 16, 15), ("finite_horizon", 3, 30), ("merging", 10, 20)])
+                                           ("local_opt", 16, 15), ("finite_horizon", 3, 30), ("merging", 10, 20),
+                                           ("merging", 25, 12), ("local_opt", 25, 12)])
 def test_all_scan_variants_bitwise(oracle, eng_factory, hip, scan_mode, name, H, n_iter):
-    """scan_mode 1 (LDS windows), 2 (DPP row shifts, H <= 16) and 3 (all K initialisations in one
-    wavefront, K*H <= 64) are three implementations of the same recurrences; all must reproduce the
-    oracle bit for bit, plans, losses and episodes.  (Horizons without a specialised kernel run the
-    generic LDS kernel whatever the mode.)"""
+    """scan_mode 1 (LDS windows), 2 (DPP row shifts, H <= 16), 3 (all K initialisations in one
+    wavefront, K*H <= 64) and 4 (a lane owns a chunk of 5 steps) are four implementations of the same
+    recurrences; all must reproduce the oracle bit for bit, plans, losses and episodes.  (A shape without
+    the requested kernel runs the LDS kernel.)"""
     scn = scenarios.SCENARIOS[name](horizon=H, n_iter=n_iter)
     eng = eng_factory(scn)
     B = 21
@@ -188,7 +189,7 @@ def test_all_scan_variants_bitwise(oracle, eng_factory, hip, scan_mode, name, H,
     assert_bitwise(ro["returns"], rr["returns"], "returns")
 
 
-@pytest.mark.parametrize("segs,mode", [(1, 0), (2, 0), (6, 1), (0, 0), (1, 3), (2, 3), (3, 2)])
+@pytest.mark.parametrize("segs,mode", [(1, 0), (2, 0), (6, 1), (0, 0), (1, 3), (2, 3), (3, 2), (0, 4), (3, 4), (1, 4)])
 def test_results_do_not_depend_on_packing(oracle, eng_factory, hip, segs, mode):
     """segs_per_wave (trajectories per wavefront) is a pure performance knob: packed lanes, parked
     lanes and the wave-uniform feature skips must not change a bit."""
@@ -218,7 +219,7 @@ def test_results_do_not_depend_on_packing(oracle, eng_factory, hip, segs, mode):
         eng.set_option("nonsense", 1)
 
 
-@pytest.mark.parametrize("segs,mode", [(1, 0), (0, 0), (6, 1), (0, 1), (1, 3), (2, 3), (2, 2)])
+@pytest.mark.parametrize("segs,mode", [(1, 0), (0, 0), (6, 1), (0, 1), (1, 3), (2, 3), (2, 2), (0, 4), (2, 4)])
 def test_non_finite_trajectories_bitwise(oracle, eng_factory, hip, segs, mode):
     """Hard braking drives v negative and the drag term -f*v^2 then runs away to -inf inside the
     horizon (car_dynamics_step has no speed floor): rewards become -inf, losses +inf, some adjoints
@@ -285,7 +286,7 @@ def test_errors_are_reported_not_thrown(hip, eng_factory):
     assert b"n_cars" in hip.ocd_last_error()
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
 def test_finite_speed_with_overflowing_drag_bitwise(oracle, eng_factory, mode):
     """|v| ~ 3e19 is finite but fr * v * v overflows: the LDS variant's masked fma needs a finite increment
     (fma(-inf, 0, v) is NaN), so it must take its exact-select fallback exactly when the other variants

@@ -76,7 +76,7 @@ def test_random_descriptor_bitwise(hip, oracle, case):
     scn = random_scenario(rng, H, NO, L)
     d = scn.desc
     eng = Engine(scn, "cuda:0")
-    eng.set_option("scan_mode", int(rng.integers(0, 4)))            # any variant the shape allows
+    eng.set_option("scan_mode", int(rng.integers(0, 5)))            # any variant the shape allows
     phase = int(rng.integers(0, 3))
     eng.set_option("reset_phase", phase)
     B = int(rng.integers(1, 12))

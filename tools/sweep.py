@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--segs", default="0")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--pop-scale", type=int, default=1, help="multiply the population (bigger batches)")
+    ap.add_argument("--pop", type=int, default=0, help="override the population (candidates)")
     ap.add_argument("--no-skips", type=int, default=0)
     ap.add_argument("--no-unify", type=int, default=0)
     ap.add_argument("--scan-mode", default="0", help="comma list of scan modes: 0 auto, 1 LDS windows, 2 DPP rows, 3 all inits in one wavefront")
@@ -26,7 +27,7 @@ def main():
     for cfg in [int(c) for c in a.configs.split(",")]:
         c = scenarios.BASELINE_CONFIGS[cfg]
         scn = scenarios.SCENARIOS[c["scenario"]](horizon=c["horizon"])
-        P, N, S = c["pop"] * a.pop_scale, c["n_inits"], scn.desc.n_samples
+        P, N, S = (a.pop or c["pop"]) * a.pop_scale, c["n_inits"], scn.desc.n_samples
         inits = scn.init_dist.sample(N, seed=1000 + cfg)
         w32 = np.stack([scenarios.planner_weights_fp32(x) for x in scn.candidate_weights(P, seed=2000 + cfg)])
         eng = Engine(scn, "cuda:0")
@@ -37,11 +38,13 @@ def main():
         eng.set_option("no_feature_skips", a.no_skips)
         eng.set_option("no_unified_features", a.no_unify)
         for mode in [int(m) for m in a.scan_mode.split(",")]:
-            if (mode == 2 and c["horizon"] > 16) or (mode == 3 and scn.desc.n_ctrl_inits * c["horizon"] > 64):
+            if (mode == 2 and c["horizon"] > 16) or (mode == 3 and scn.desc.n_ctrl_inits * c["horizon"] > 64) or \
+                    (mode == 4 and c["horizon"] % 5):
                 continue
             eng.set_option("scan_mode", mode)
             for segs in [int(s) for s in a.segs.split(",")]:
-                if (mode == 2 and segs > 4) or (mode == 3 and segs > 64 // (scn.desc.n_ctrl_inits * c["horizon"])):
+                if (mode == 2 and segs > 4) or (mode == 3 and segs > 64 // (scn.desc.n_ctrl_inits * c["horizon"])) or \
+                        (mode == 4 and segs > 64 // (scn.desc.n_ctrl_inits * (c["horizon"] // 5))):
                     continue
                 eng.set_option("segs_per_wave", segs)
                 eng.time_rollout(init_dev, w_dev, 0, E, ret, 1)

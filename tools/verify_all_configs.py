@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", default="2,3,4,5")
     ap.add_argument("--threads", type=int, default=16)
+    ap.add_argument("--scan-mode", type=int, default=0, help="force a kernel variant (ocd_scenario_set_option scan_mode)")
     a = ap.parse_args()
     import oracle_lib
     from l4dc_mpc_ocd_amd import scenarios
@@ -28,7 +29,9 @@ def main():
         scn, inits, cands = scenarios.baseline_config(cfg)
         w32 = np.stack([scenarios.planner_weights_fp32(c) for c in cands])
         t0 = time.perf_counter()
-        got = Engine(scn, "cuda:0").rollout(inits, w32)["returns"]
+        eng = Engine(scn, "cuda:0")
+        eng.set_option("scan_mode", a.scan_mode)
+        got = eng.rollout(inits, w32)["returns"]
         t1 = time.perf_counter()
         ref = np.empty_like(got)
         E = got.size
