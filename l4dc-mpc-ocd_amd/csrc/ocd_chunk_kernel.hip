@@ -84,6 +84,7 @@ mpc_chunk_kernel(const KernelParams p)
         for (int k = 0; k < OCD_MAX_FEATURES; ++k) w[k] = (wp && k < D) ? wp[k] : 0.0f;
         tp_idx = p.sample_fixed;
     }
+    const LaneGradConst<L> lgc = lane_grad_const<L>(w);
     float wd[OCD_MAX_FEATURES];
 #pragma unroll
     for (int k = 0; k < OCD_MAX_FEATURES; ++k) wd[k] = d.designer_weights[k];
@@ -288,7 +289,7 @@ mpc_chunk_kernel(const KernelParams p)
                         if (p.no_skips || multi != 0ull || (p.no_unify && (has_f || has_col))) {
                             rw[s] = reward_state<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], q[s], nullptr, true, true);
                         } else if (has_f || has_col) {
-                            rw[s] = reward_one<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], nc, nf, has_col, has_f, q[s], pkc);
+                            rw[s] = reward_one<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], nc, nf, has_col, has_f, q[s], pkc, lgc, live_mask);
                         } else {
                             rw[s] = reward_state<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], q[s], nullptr, false, false);
                         }

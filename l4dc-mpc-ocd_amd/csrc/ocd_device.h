@@ -293,6 +293,25 @@ __device__ __forceinline__ float reward_state(const ocd_scenario_desc &d, const 
     return r;
 }
 
+// Lane-feature gradient factors of one trajectory (its weights are fixed for the whole episode): the chain
+//   g = w_l (+ w_min when lane l is the sole minimum) ; g_d2 = g * 10 ; (g_d2 * 2)
+// of the backward pass evaluated once, outside the SGD loop (same operations, same order, hoisted).
+template <int L>
+struct LaneGradConst { float g0[L > 0 ? L : 1], g1[L > 0 ? L : 1]; };
+
+template <int L>
+__device__ __forceinline__ LaneGradConst<L> lane_grad_const(const float (&w)[OCD_MAX_FEATURES])
+{
+    LaneGradConst<L> c;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        c.g0[l] = (w[1 + l] * 10.0f) * 2.0f;
+        c.g1[l] = ((w[1 + l] + inv_count(1) * w[L + 1]) * 10.0f) * 2.0f;
+        asm volatile("" : "+v"(c.g0[l]), "+v"(c.g1[l]));     // keep the products: do not fold the select back in
+    }
+    return c;
+}
+
 // ---------------------------------------------------------------- reward, one active feature per lane
 // Precondition (WAVE-UNIFORM, proved by the caller with needs_fence / needs_collision1): every live lane
 // has AT MOST ONE active feature among {fence, collision with scripted car 0, ..., car NO-1}; `is_f`
@@ -313,7 +332,8 @@ __device__ __forceinline__ float reward_one(const ocd_scenario_desc &d, const fl
                                             float x, float y, float v, float sn, float cn,
                                             const BumpGeom (&bg)[NO > 0 ? NO : 1], const bool (&nc)[NO > 0 ? NO : 1],
                                             const bool is_f, const bool has_col, const bool has_f, Q4 &q,
-                                            const PkConsts &pkc)
+                                            const PkConsts &pkc, const LaneGradConst<L> &lgc,
+                                            const unsigned long long live_mask)
 {
     static_assert(L > 0 && NO > 0, "lane-feature reward only");
     const float tgt = d.target_speed;
@@ -418,18 +438,29 @@ __device__ __forceinline__ float reward_one(const ocd_scenario_desc &d, const fl
     const float g_sn = g_dv * v;
     q.qth = g_sn * cn;
 
+    // reduce_min over the lanes: the gradient goes to the minimum, split equally among exact ties.  Ties are
+    // rare: unless some live lane has one (wave-uniform test), the per-lane factors come precomputed.
+    bool tie[L];
     int ntie_min = 0;
 #pragma unroll
-    for (int l = 0; l < L; ++l) ntie_min += (pl[l] == pmin) ? 1 : 0;
+    for (int l = 0; l < L; ++l) { tie[l] = pl[l] == pmin; ntie_min += tie[l] ? 1 : 0; }
     float qx = 0.0f;
-    const float min_share = inv_count(ntie_min) * w_min;
+    if ((__ballot(ntie_min > 1) & live_mask) == 0ull) {
 #pragma unroll
-    for (int l = 0; l < L; ++l) {
-        float gl = w[1 + l];
-        gl = (pl[l] == pmin) ? (gl + min_share) : gl;
-        const float g_d2 = gl * 10.0f;
-        const float g_r = (g_d2 * 2.0f) * rl[l];
-        qx = qx + g_r * -1.0f;
+        for (int l = 0; l < L; ++l) {
+            const float g_r = (tie[l] ? lgc.g1[l] : lgc.g0[l]) * rl[l];
+            qx = qx + g_r * -1.0f;
+        }
+    } else {
+        const float min_share = inv_count(ntie_min) * w_min;
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            float gl = w[1 + l];
+            gl = tie[l] ? (gl + min_share) : gl;
+            const float g_d2 = gl * 10.0f;
+            const float g_r = (g_d2 * 2.0f) * rl[l];
+            qx = qx + g_r * -1.0f;
+        }
     }
     // collision adjoint up to the division by the bump width (zero on fence lanes)
     const float col_share = ((NO == 1) ? 1.0f : ((pcol == 0.0f) ? inv_count(NO) : 1.0f)) * w_col;

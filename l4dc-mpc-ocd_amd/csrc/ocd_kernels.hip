@@ -191,6 +191,7 @@ mpc_kernel(const KernelParams p)
         for (int k = 0; k < OCD_MAX_FEATURES; ++k) w[k] = (wp && k < D) ? wp[k] : 0.0f;
         tp_idx = p.sample_fixed;
     }
+    const LaneGradConst<L> lgc = lane_grad_const<L>(w);   // lane-feature gradient factors of this trajectory
     float wd[OCD_MAX_FEATURES];               // designer weights (uniform)
 #pragma unroll
     for (int k = 0; k < OCD_MAX_FEATURES; ++k) wd[k] = d.designer_weights[k];
@@ -433,7 +434,7 @@ mpc_kernel(const KernelParams p)
                     r = reward_state<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, true, true);
                     OCD_STAMP(5); OCD_STAMP_COUNT(12);     // every feature
                 } else if (has_f || has_col) {
-                    r = reward_one<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, nc, nf, has_col, has_f, q, pkc);
+                    r = reward_one<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, nc, nf, has_col, has_f, q, pkc, lgc, feat_mask);
                     OCD_STAMP(6); OCD_STAMP_COUNT(13);     // one feature per lane
                 } else {
                     r = reward_state<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, false, false);
