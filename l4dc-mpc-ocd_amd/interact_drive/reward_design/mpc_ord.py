@@ -15,7 +15,7 @@ from .. import experiments  # noqa: F401
 from ..experiments._sampling import make_get_init_state
 from .._describe import describe, engine_for
 from ... import sharding
-from ...scenarios import planner_weights_fp32
+from ...scenarios import planner_weights_fp32, planner_weights_fp32_batch
 
 
 class list2(list):  # mutable list that can carry a .seed attribute (mpc_ord.py:10-12)
@@ -75,7 +75,7 @@ class MPC_ORD:
         import torch
         import torch.distributed as dist
         eng = self._engine()
-        w32 = np.stack([planner_weights_fp32(w) for w in weights_2d])
+        w32 = planner_weights_fp32_batch(np.asarray([np.asarray(w, dtype=np.float64).reshape(-1) for w in weights_2d]))
         init = np.asarray(inits, dtype=np.float32).reshape(-1, 4)
         P, N, S = w32.shape[0], init.shape[0], self.num_samples
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
@@ -124,10 +124,10 @@ class MPC_ORD:
         self.last_returns = ret
         P, N, S = ret.shape
         cost = sharding.fitness_from_returns(ret.reshape(-1), P, N, S)
-        for p in range(P):
-            wn = W[p] / np.linalg.norm(W[p])
-            self.history.append((wn, -cost[p]))
-            self.iter += 1
+        n2 = np.array([row.dot(row) for row in W])               # np.linalg.norm(row) == sqrt(row.dot(row))
+        Wn = W / np.sqrt(n2)[:, None]
+        self.history.extend(zip(Wn, -cost))
+        self.iter += P
         if self.should_save_history and self.save_path is not None:
             self.save_history()
         return cost

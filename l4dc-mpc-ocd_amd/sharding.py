@@ -58,11 +58,8 @@ def fitness_from_returns(returns, P: int, N: int, S: int) -> np.ndarray:
     casting, mpc_ord.py:126,137); then / num_samples and negated (mpc_ord.py:139,151).
     """
     r = np.asarray(returns, dtype=np.float32).reshape(P, N, S)
-    per_init = np.zeros((P, N), dtype=np.float32)
-    for s in range(S):
-        per_init = (per_init + r[:, :, s]).astype(np.float32)
-    total = np.zeros(P, dtype=np.float64)
-    for n in range(N):
-        total = total + per_init[:, n].astype(np.float64)
+    # add.accumulate is strictly sequential along the axis (np.sum is pairwise and would round differently)
+    per_init = r[:, :, 0] if S == 1 else np.add.accumulate(r, axis=2, dtype=np.float32)[:, :, -1]
+    total = np.add.accumulate(per_init.astype(np.float64), axis=1)[:, -1]
     total = total / S
     return -total

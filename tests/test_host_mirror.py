@@ -115,6 +115,15 @@ def test_fitness_accumulation_types():
     assert cost[0] == exp0 and cost[1] == -(0.75 + 3.0) / 2
 
 
+def test_batched_weight_normalisation_is_bitwise_the_per_row_one():
+    rng = np.random.default_rng(3)
+    for D in (6, 7, 8):
+        W = rng.standard_normal((400, D)) * 10 ** rng.uniform(-3, 3, (400, 1))
+        a = scenarios.planner_weights_fp32_batch(W)
+        b = np.stack([scenarios.planner_weights_fp32(w) for w in W])
+        assert a.dtype == np.float32 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
 def test_planner_weight_normalisation_chain():
     w = np.array([-5, 0., 0., 0., -6., -50, -50])
     w32 = scenarios.planner_weights_fp32(w)
