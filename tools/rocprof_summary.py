@@ -54,14 +54,14 @@ def counters_json(round_name, out_dir):
                 try:
                     for name, cnt, avg, grid, wg in cur.execute(
                             "select counter_name, count(*), avg(value), max(grid_size), max(workgroup_size) "
-                            "from counters_collection where kernel_name like '%mpc_kernel%' group by counter_name"):
+                            "from counters_collection where kernel_name like '%mpc_%kernel%' group by counter_name"):
                         vals[name] = avg
                         vals["grid_size"], vals["workgroup_size"] = grid, wg
                 except sqlite3.Error:
                     pass
                 if kind == "stats":
                     try:
-                        for name, calls, avg in cur.execute("select name, total_calls, average from top_kernels where name like '%mpc_kernel%'"):
+                        for name, calls, avg in cur.execute("select name, total_calls, average from top_kernels where name like '%mpc_%kernel%'"):
                             vals["kernel_avg_us"], vals["kernel_calls"], vals["kernel_name"] = avg, calls, name
                     except sqlite3.Error:
                         pass
