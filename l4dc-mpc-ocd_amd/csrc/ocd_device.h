@@ -46,6 +46,16 @@ __device__ __forceinline__ float f_bwd(float g, float shape, const FTape &tp, fl
     return tp.pos ? g_tc : 0.0f;
 }
 
+// f_bwd without its first select: where pos is false the result is 0 through the LAST select whatever the
+// product chain computed, where it is true both selects pass the value -- same result, one select fewer
+__device__ __forceinline__ float f_bwd_gated(float g, float shape, const FTape &tp, float k)
+{
+    const float g_m = g * tp.e;
+    const float g_u = g_m * k;
+    const float g_tc = g_u * shape;
+    return tp.pos ? g_tc : 0.0f;
+}
+
 // smooth_threshold (math_utils.py:87-95)
 struct ThrTape { FTape t1, t2; float den, S; };
 
@@ -407,7 +417,7 @@ __device__ __forceinline__ float reward_one(const ocd_scenario_desc &d, const fl
         den = F1 + F2;
         S = F1 / den;
         ax = (x < 0.0f) ? -x : x;
-        Ssum = is_f ? S : 0.0f;
+        Ssum = GRAD ? S : (is_f ? S : 0.0f);       // GRAD: only the fence lanes' adjoint reads it (selected at the end)
         pf = is_f ? (S * ax) : 0.0f;
     }
     // bump outputs (meaningful on the other lanes)
@@ -464,15 +474,30 @@ __device__ __forceinline__ float reward_one(const ocd_scenario_desc &d, const fl
     }
     // collision adjoint up to the division by the bump width (zero on fence lanes)
     const float col_share = ((NO == 1) ? 1.0f : ((pcol == 0.0f) ? inv_count(NO) : 1.0f)) * w_col;
-    const float g_bx = is_f ? 0.0f : (col_share * byv);
-    const float g_by = is_f ? 0.0f : (col_share * bxv);
-    const float gx_e = condx ? g_bx : 0.0f;
-    const float gx_q = (gx_e * e1) * k1;
+    // (no select on is_f / cond at the head of these chains: on fence lanes the results are discarded by the
+    //  selects below, and where cond is false the last select of a chain yields 0 whatever it computed)
+#ifdef OCD_NO_PACKED
+    const float g_bx = col_share * byv;
+    const float g_by = col_share * bxv;
+    const float gx_q = (g_bx * e1) * k1;
     const float gx_xc = ((-gx_q) * 2.0f) * xcx;
-    const float g_znx = condx ? gx_xc : 0.0f;
-    const float gy_e = condy ? g_by : 0.0f;
-    const float gy_q = (gy_e * e2) * k2;
+    const float gy_q = (g_by * e2) * k2;
     const float gy_xc = ((-gy_q) * 2.0f) * xcy;
+#else
+    // the x and y chains two-wide: (col_share * (byv, bxv)) * (e1, e2) * (k1, k2), (-.) * 2, * (xcx, xcy)
+    v2f GXY;
+    {
+        const v2f B = {bxv, byv}, CS = splat2(col_share), XC = {xcx, xcy};
+        asm("v_pk_mul_f32 %[g], %[b], %[cs] op_sel:[1,0] op_sel_hi:[0,1]\n"     // (byv, bxv) * col_share
+            "v_pk_mul_f32 %[g], %[g], %[e]\n"
+            "v_pk_mul_f32 %[g], %[g], %[k]\n"
+            "v_pk_mul_f32 %[g], %[g], 2.0 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]\n"
+            "v_pk_mul_f32 %[g], %[g], %[xc]\n"
+            : [g] "=&v"(GXY) : [b] "v"(B), [cs] "v"(CS), [e] "v"(E), [k] "v"(Kk), [xc] "v"(XC));
+    }
+    const float gx_xc = GXY.x, gy_xc = GXY.y;
+#endif
+    const float g_znx = condx ? gx_xc : 0.0f;
     const float g_zny = condy ? gy_xc : 0.0f;
     // fence adjoint up to its two divisions by den
     const float g_Ssum = w_f * ax;
@@ -491,9 +516,9 @@ __device__ __forceinline__ float reward_one(const ocd_scenario_desc &d, const fl
         FTape t1, t2;
         t1.pos = pos1; t1.m = m1; t1.e = e1; t1.u = u1;
         t2.pos = pos2; t2.m = m2; t2.e = e2; t2.u = u2;
-        const float ga = f_bwd(q1, d.fence_shape, t1, k1);
-        const float gb = f_bwd(g_den, d.fence_shape, t1, k1);
-        const float gc = f_bwd(g_den, d.fence_shape, t2, k2);
+        const float ga = f_bwd_gated(q1, d.fence_shape, t1, k1);
+        const float gb = f_bwd_gated(g_den, d.fence_shape, t1, k1);
+        const float gc = f_bwd_gated(g_den, d.fence_shape, t2, k2);
         const float g_z = (ga + gb) + (-gc);
         const float sgn = (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f);
         qx_f = (qx + (side_p ? g_z : -g_z)) + g_ax * sgn;
