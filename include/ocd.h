@@ -161,6 +161,7 @@ int32_t ocd_scenario_set_option(ocd_scenario *scn, const char *name, int32_t val
  *   grid0/1/2 [n0]/[n1]/[n2]  ascending cell boundaries (ValueFeature.disc_grid), HOST pointers
  *   values    [n0, n1, n2]    one time slice of v_grids (v_grids[t]), HOST pointer
  * The handle copies the table (to every device it launches on).  values == NULL removes it.
+ * Not to be called while launches that use the handle are still in flight (the device copy is freed).
  */
 int32_t ocd_scenario_set_leaf_value(ocd_scenario *scn, const float *grid0, int32_t n0,
                                     const float *grid1, int32_t n1, const float *grid2, int32_t n2,

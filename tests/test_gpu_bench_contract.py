@@ -1,0 +1,41 @@
+"""bench.py on a real GPU: one JSON line with the contract's keys, the roofline / cpu_baseline objects,
+and numbers that are consistent with each other."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_json_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "cma_generation_ms", "config2"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert d["vs_baseline"] is None and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert "config 3" in d["config"]["workload"] and "model" not in d["config"]
+    assert d["config"]["episodes_per_generation"] == 2048
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    # achieved = algorithmic bytes per launch / the kernel's launch duration measured with HIP events
+    assert abs(rf["achieved"] - 2048 * rf["algorithmic_bytes_per_episode"] / (rf["kernel_ms"] * 1e-3) / 1e9) < 1e-9
+    assert rf["traffic"] is None or rf["traffic"] > 0
+    # the step (launch + D2H + float64 reduction) cannot be faster than the kernel alone, nor much slower
+    assert rf["kernel_ms"] <= d["ms_per_step"] * 1.02 and d["ms_per_step"] < rf["kernel_ms"] + 0.5
+    assert abs(d["value"] - 2048 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "episodes/s" and cb["sample"]
+    assert d["cma_generation_ms"] > rf["kernel_ms"] * 0.9
+    assert d["config2"]["episodes_per_generation"] == 128 and d["config2"]["value"] > 0
+    assert 0 < d["valu"]["frac"] < 1
