@@ -143,6 +143,7 @@ void ocd_scenario_destroy(ocd_scenario *scn);
  *                (H <= 16, K wavefronts per workgroup), 3 = all K initialisations in one wavefront
  *                (K*H <= 64, wavefront shifts, no workgroup barrier), 4 = a lane owns a chunk of consecutive
  *                horizon steps (long horizons at throughput); a mode the scenario cannot use falls back to 1;
+ *   "chunk_size": horizon steps per lane of scan_mode 4 (0 = automatic among the compiled sizes);
  *   "no_unified_features": 1 = never evaluate a lane's single active feature through the shared path;
  *   "no_feature_skips": 1 = evaluate the collision and fence features even where they are provably
  *                       zero (diagnostics; default 0).

@@ -24,7 +24,7 @@ struct ocd_scenario {
     int32_t K;
     int32_t D;
     // per-handle options (ocd_scenario_set_option)
-    int32_t opt_segs = 0, opt_no_skips = 0, opt_scan_mode = 0, opt_no_unify = 0, opt_reset_phase = 0;
+    int32_t opt_segs = 0, opt_no_skips = 0, opt_scan_mode = 0, opt_no_unify = 0, opt_reset_phase = 0, opt_chunk = 0;
     // The planner's fixed view of the scripted cars' plans (planner_car.py:58-80:
     // plan[j] from index 0, then the assumed default) is a scenario constant; rollouts
     // read it from a small device buffer owned by the handle, one per device.
@@ -150,6 +150,7 @@ void base_params(const ocd_scenario *scn, ocd::KernelParams &p)
     p.scan_mode = scn->opt_scan_mode;
     p.no_unify = scn->opt_no_unify;
     p.reset_phase = scn->opt_reset_phase;
+    p.chunk_size = scn->opt_chunk;
 }
 
 int32_t launch(const ocd_scenario *scn, ocd::KernelParams &p, void *hip_stream)
@@ -197,6 +198,11 @@ int32_t ocd_scenario_set_option(ocd_scenario *scn, const char *name, int32_t val
     if (std::strcmp(name, "scan_mode") == 0) {
         if (value < 0 || value > 4) return fail(OCD_ERR_INVALID_ARG, "scan_mode %d out of [0,4]", value);
         scn->opt_scan_mode = value;
+        return OCD_OK;
+    }
+    if (std::strcmp(name, "chunk_size") == 0) {
+        if (value < 0 || value > OCD_MAX_HORIZON) return fail(OCD_ERR_INVALID_ARG, "chunk_size %d out of [0,%d]", value, OCD_MAX_HORIZON);
+        scn->opt_chunk = value;
         return OCD_OK;
     }
     if (std::strcmp(name, "no_unified_features") == 0) { scn->opt_no_unify = value ? 1 : 0; return OCD_OK; }

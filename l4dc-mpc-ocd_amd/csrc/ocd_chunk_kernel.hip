@@ -25,10 +25,14 @@
 #include "ocd_kernels.h"
 #include "ocd_lane.h"
 
+#ifndef OCD_CHUNK_OCC
+#define OCD_CHUNK_OCC
+#endif
+
 namespace ocd {
 
 template <int HT, int NO, int L, int S>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) OCD_CHUNK_OCC
 mpc_chunk_kernel(const KernelParams p)
 {
     static_assert(HT % S == 0, "the chunk size divides the horizon");
@@ -473,12 +477,36 @@ static hipError_t launch_chunk(const KernelParams &p_in, hipStream_t st)
     return hipGetLastError();
 }
 
-#define OCD_CCASE(HH, NN, LL, SS) if (H == HH && NO == NN && L == LL) { *chunk = SS; if (launch) return launch_chunk<HH, NN, LL, SS>(p, st); return hipSuccess; }
-
-// chunk = 0 and hipSuccess: no chunked kernel for this shape.  launch = false only asks.
-hipError_t launch_chunk_dispatch(int H, int NO, int L, const KernelParams &p, hipStream_t st, bool launch, int *chunk)
+// cost estimate of chunk size S for n trajectories: full rounds of wavefronts x instructions per pass
+static double chunk_cost(int H, int K, int NO, int S, long long n, long long slots)
 {
-    *chunk = 0;
+    const int NC = H / S;
+    const int cap = 64 / (K * NC);
+    if (cap < 1) return 1e30;
+    const long long waves = (n + cap - 1) / cap;
+    const long long rounds = (waves + slots - 1) / slots;
+    // recurrences + lane-parallel work per step (instructions; more scripted cars = more feature work)
+    const double per_pass = (double)(NC - 1) * S * 20.0 + S * (350.0 + 200.0 * (NO > 1 ? NO - 1 : 0)) + 60.0;
+    return (double)(rounds < 1 ? 1 : rounds) * per_pass;
+}
+
+#define OCD_CPICK(HH, NN, LL, SS)                                                                         \
+    if (H == HH && NO == NN && L == LL && (want == 0 || want == SS)) {                                    \
+        const double c_ = chunk_cost(HH, p.K, NN, SS, p.n_problems, slots);                                   \
+        if (c_ < best_cost) { best_cost = c_; best = SS; }                                                \
+    }
+#define OCD_CCASE(HH, NN, LL, SS) if (H == HH && NO == NN && L == LL && best == SS) return launch_chunk<HH, NN, LL, SS>(p, st);
+
+hipError_t launch_chunk_dispatch(int H, int NO, int L, const KernelParams &p, hipStream_t st, bool launch, int want,
+                                 int *chunk)
+{
+    // two wavefronts per SIMD fit (190-235 VGPRs)
+    const long long slots = 2ll * 4ll * (p.n_cus > 0 ? p.n_cus : 256);
+    int best = 0;
+    double best_cost = 1e29;
+    OCD_CHUNK_TABLE(OCD_CPICK)
+    *chunk = best;
+    if (!launch || best == 0) return hipSuccess;
     OCD_CHUNK_TABLE(OCD_CCASE)
     return hipSuccess;
 }

@@ -60,6 +60,7 @@ struct KernelParams {
     int32_t no_skips;          // diagnostics: 1 = always evaluate collision and fence features
     int32_t scan_mode;         // 0 = automatic, 1 = V_LDS, 2 = V_ROW, 3 = V_SEG, 4 = V_CHUNK
     int32_t no_unify;          // diagnostics: 1 = never use the one-feature-per-lane evaluation
+    int32_t chunk_size;        // V_CHUNK: 0 = pick the compiled chunk size by cost, else force this one
     int32_t n_cus;             // compute units of the device (launch shape heuristics)
     unsigned long long *debug; // diagnostic builds only (OCD_STAMPS): per-wavefront cycle totals, else nullptr
 };
@@ -82,15 +83,18 @@ struct KernelParams {
     X(2, 1) X(2, 2) X(2, 3) X(2, 4)                                                           \
     X(3, 1) X(3, 2) X(3, 3) X(3, 4)
 
-// (horizon H, scripted cars NO, lanes L, chunk S) with a chunked kernel (V_CHUNK)
+// (horizon H, scripted cars NO, lanes L, chunk S) with a chunked kernel (V_CHUNK); several S per shape allowed
 #define OCD_CHUNK_TABLE(X)                                                                    \
-    X(10, 1, 3, 5) X(15, 1, 3, 5) X(25, 1, 3, 5)                                              \
-    X(10, 2, 2, 5) X(15, 2, 2, 5)                                                             \
+    X(10, 1, 3, 5) X(15, 1, 3, 5) X(15, 1, 3, 3) X(25, 1, 3, 5)                               \
+    X(10, 2, 2, 5) X(15, 2, 2, 5) X(15, 2, 2, 3)                                              \
     X(10, 2, 3, 5) X(25, 2, 3, 5)
 
 hipError_t launch_mpc_dispatch(int H, int NO, int L, const KernelParams &p, hipStream_t st, bool *supported);
-// V_CHUNK: *chunk = the chunk size compiled for this shape (0 = none); launches when `launch`
-hipError_t launch_chunk_dispatch(int H, int NO, int L, const KernelParams &p, hipStream_t st, bool launch, int *chunk);
+// V_CHUNK: *chunk = the chunk size it would use / used for this shape (0 = none): the compiled size that
+// packs the batch into the fewest full rounds of wavefronts, or `want` (> 0) if that size is compiled;
+// launches when `launch`
+hipError_t launch_chunk_dispatch(int H, int NO, int L, const KernelParams &p, hipStream_t st, bool launch, int want,
+                                 int *chunk);
 hipError_t launch_reward(int NO, int L, const KernelParams &p, float *feats, float *rew, hipStream_t st, bool *supported);
 // R(u) and dR/du for caller-supplied controls [B,H,2] (naive_planner.py:33-77)
 hipError_t launch_objective(int NO, int L, const KernelParams &p, const float *controls, float *reward_out,

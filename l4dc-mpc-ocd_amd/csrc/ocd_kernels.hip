@@ -856,7 +856,7 @@ static int clampi(long long v, long long lo, long long hi) { return (int)(v < lo
 //   * V_SEG (single-wavefront workgroups spread evenly over the SIMDs, no workgroup barrier) while it gives
 //     at most one wavefront per SIMD, or up to four when it packs lanes as densely as V_LDS (K*H close to 64);
 //   * V_CHUNK once its wavefronts (S times the problems each) fill enough of the chip: from 3/4 of the SIMDs
-//     at H >= 20, where the O(H^2) recurrence work it removes dominates, later for shorter horizons;
+//     at H >= 20, where the O(H^2) recurrence work it removes dominates, one per SIMD at H >= 15, three below;
 //   * else V_LDS, densest packing at one lane per step, LDS latency hidden by the other wavefronts.
 // scan_mode 1..4 and segs_per_wave force the choice (tests, sweeps).
 template <int HT, int NO, int L>
@@ -871,7 +871,7 @@ static hipError_t launch_mpc(const KernelParams &p_in, hipStream_t st)
     const int seg_cap = (HT > 0 && K * H <= 64) ? 64 / (K * H) : 0;    // V_SEG trajectories per wavefront
     const int row_cap = (HT > 0 && H <= 16) ? 4 : 0;                   // V_ROW
     int chunk = 0;                                                     // V_CHUNK: chunk size compiled for this shape
-    (void)launch_chunk_dispatch(H, NO, L, p, st, false, &chunk);
+    (void)launch_chunk_dispatch(H, NO, L, p, st, false, p.chunk_size, &chunk);
     if (chunk && 64 / (K * (H / chunk)) < 1) chunk = 0;
     int variant = V_LDS;
     if (p.leaf.values) variant = V_LDS;                                // the terminal value lives in the generic kernel
@@ -882,13 +882,13 @@ static hipError_t launch_mpc(const KernelParams &p_in, hipStream_t st)
         const long long waves_seg = seg_cap ? ceil_div(n, seg_cap) : 0;
         const long long waves_lds = ceil_div(n, G.SEGS) * K;
         const long long waves_chunk = chunk ? ceil_div(n, 64 / (K * (H / chunk))) : 0;
-        const long long chunk_from = (H >= 20) ? (3 * simds) / 4 : ((H >= 15) ? 2 * simds : 3 * simds);
+        const long long chunk_from = (H >= 20) ? (3 * simds) / 4 : ((H >= 15) ? simds : 3 * simds);
         if (row_cap && n * K <= simds) variant = V_ROW;
         else if (seg_cap && (waves_seg <= simds || (waves_seg * 20 <= waves_lds * 21 && waves_seg <= 4 * simds))) variant = V_SEG;
         else if (chunk && waves_chunk >= chunk_from) variant = V_CHUNK;
         else if (row_cap && ceil_div(n, row_cap) * K <= simds) variant = V_ROW;
     }
-    if (variant == V_CHUNK) return launch_chunk_dispatch(H, NO, L, p, st, true, &chunk);
+    if (variant == V_CHUNK) return launch_chunk_dispatch(H, NO, L, p, st, true, p.chunk_size, &chunk);
     int segs;
     if (variant == V_ROW) segs = p.segs_used > 0 ? clampi(p.segs_used, 1, row_cap) : clampi(ceil_div(n * K, simds), 1, row_cap);
     else if (variant == V_SEG) segs = p.segs_used > 0 ? clampi(p.segs_used, 1, seg_cap) : clampi(ceil_div(n, simds), 1, seg_cap);

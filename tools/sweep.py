@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--pop-scale", type=int, default=1, help="multiply the population (bigger batches)")
     ap.add_argument("--pop", type=int, default=0, help="override the population (candidates)")
+    ap.add_argument("--chunk", type=int, default=0, help="chunk_size option (scan mode 4)")
     ap.add_argument("--no-skips", type=int, default=0)
     ap.add_argument("--no-unify", type=int, default=0)
     ap.add_argument("--scan-mode", default="0", help="comma list of scan modes: 0 auto, 1 LDS windows, 2 DPP rows, 3 all inits in one wavefront")
@@ -36,6 +37,7 @@ def main():
         E = P * N * S
         ret = torch.empty(E, dtype=torch.float32, device="cuda")
         eng.set_option("no_feature_skips", a.no_skips)
+        eng.set_option("chunk_size", a.chunk)
         eng.set_option("no_unified_features", a.no_unify)
         for mode in [int(m) for m in a.scan_mode.split(",")]:
             if (mode == 2 and c["horizon"] > 16) or (mode == 3 and scn.desc.n_ctrl_inits * c["horizon"] > 64) or \
@@ -44,7 +46,7 @@ def main():
             eng.set_option("scan_mode", mode)
             for segs in [int(s) for s in a.segs.split(",")]:
                 if (mode == 2 and segs > 4) or (mode == 3 and segs > 64 // (scn.desc.n_ctrl_inits * c["horizon"])) or \
-                        (mode == 4 and segs > 64 // (scn.desc.n_ctrl_inits * (c["horizon"] // 5))):
+                        (mode == 4 and segs > 64 // (scn.desc.n_ctrl_inits * (c["horizon"] // (a.chunk or 5)))):
                     continue
                 eng.set_option("segs_per_wave", segs)
                 eng.time_rollout(init_dev, w_dev, 0, E, ret, 1)
