@@ -32,13 +32,32 @@ CASES = [
     ("replanning_h5", dict(scenario="replanning", horizon=5), 2, 2),
     ("replanning_h15", dict(scenario="replanning", horizon=15), 1, 1),
     ("merging_h5", dict(scenario="merging", horizon=5), 1, 2),
+    ("merging_h25", dict(scenario="merging", horizon=25, n_iter=40), 1, 1),
+    # terminal value (leaf_evaluation): the table is part of the fixture
+    ("finite_horizon_h5_leaf", dict(scenario="finite_horizon", horizon=5, leaf=True), 2, 2),
 ]
+
+
+def leaf_table(seed):
+    """A synthetic ValueFeature table: (disc_grid, v_grid[t], proj_kind)."""
+    rng = np.random.default_rng(seed)
+    grid = [np.linspace(-0.3, 0.3, 7).astype(np.float32), np.linspace(-2.0, 2.5, 12).astype(np.float32),
+            np.linspace(0.0, 2.5, 6).astype(np.float32)]
+    vals = (rng.standard_normal((7, 12, 6)) * 2 - 1).astype(np.float32)
+    return grid, vals, 1
 
 
 def make_case(name, kw, P, N, orc):
     kw = dict(kw)
+    leaf = kw.pop("leaf", False)
     scn = scenarios.SCENARIOS[kw.pop("scenario")](**kw)
     seed = sum(map(ord, name))
+    extra = {}
+    if leaf:
+        grid, vals, proj = leaf_table(seed)
+        orc.set_leaf_value(grid, vals, proj)
+        extra = dict(leaf_grid0=grid[0], leaf_grid1=grid[1], leaf_grid2=grid[2], leaf_values=vals,
+                     leaf_proj_kind=np.int32(proj))
     inits = scn.init_dist.sample(N, seed=seed).astype(np.float32)
     cands = scn.candidate_weights(P, seed=seed + 1)
     w32 = np.stack([scenarios.planner_weights_fp32(c) for c in cands])
@@ -47,7 +66,13 @@ def make_case(name, kw, P, N, orc):
     ws = ro["traj"][0, :4]
     pl = orc.plan_batch(scn.desc, ws, w32[0], other_plans=scn.other_plans())
     feats, rew = orc.reward_batch(scn.desc, ro["traj"][0], scn.designer_weights)
-    return dict(init_states=inits, cand_weights_raw=cands, cand_weights_fp32=w32,
+    # the planner's objective and gradient at the selected plans (NaivePlanner.reward_func, naive_planner.py:33-77)
+    obj = [orc.mpc_reward(scn.desc, ws[b], w32[0], pl["plans"][b], other_plans=scn.other_plans()) for b in range(len(ws))]
+    extra.update(obj_reward=np.array([o[0] for o in obj], dtype=np.float32), obj_grad=np.stack([o[1] for o in obj]),
+                 obj_traj=np.stack([o[2] for o in obj]))
+    if leaf:
+        orc.set_leaf_value(None, None)
+    return dict(**extra, init_states=inits, cand_weights_raw=cands, cand_weights_fp32=w32,
                 returns=ro["returns"], traj=ro["traj"], ctrl=ro["ctrl"],
                 plan_world_states=ws, plan_all_plans=pl["all_plans"], plan_all_losses=pl["all_losses"],
                 plan_best_init=pl["best_init"], plan_plans=pl["plans"],

@@ -24,7 +24,14 @@ def _load(name):
 
 def _scn(kw):
     kw = dict(kw)
+    kw.pop("leaf", None)
     return scenarios.SCENARIOS[kw.pop("scenario")](**kw)
+
+
+def _leaf(g):
+    if "leaf_values" not in g.files:
+        return None
+    return [g["leaf_grid0"], g["leaf_grid1"], g["leaf_grid2"]], g["leaf_values"], int(g["leaf_proj_kind"])
 
 
 def _same(a, b):
@@ -44,6 +51,16 @@ def test_oracle_reproduces_golden(oracle, name, kw, P, N):
     w32 = np.stack([scenarios.planner_weights_fp32(c) for c in g["cand_weights_raw"]])
     assert _same(w32, g["cand_weights_fp32"])           # host-side normalisation chain is frozen too
     assert _same(scn.designer_weights, g["designer_weights"])
+    leaf = _leaf(g)
+    if leaf:
+        oracle.set_leaf_value(*leaf)
+    try:
+        _check_oracle(oracle, scn, g, w32)
+    finally:
+        oracle.set_leaf_value(None, None)
+
+
+def _check_oracle(oracle, scn, g, w32):
     ro = oracle.rollout(scn.desc, g["init_states"], w32, want_traj=True)
     assert _same(ro["returns"], g["returns"]) and _same(ro["traj"], g["traj"]) and _same(ro["ctrl"], g["ctrl"])
     pl = oracle.plan_batch(scn.desc, g["plan_world_states"], w32[0], other_plans=scn.other_plans())
@@ -51,6 +68,9 @@ def test_oracle_reproduces_golden(oracle, name, kw, P, N):
     assert np.array_equal(pl["best_init"], g["plan_best_init"])
     feats, rew = oracle.reward_batch(scn.desc, g["feat_world_states"], scn.designer_weights)
     assert _same(feats, g["feats"]) and _same(rew, g["rewards"])
+    for b in range(len(g["plan_world_states"])):
+        r, gr, tr = oracle.mpc_reward(scn.desc, g["plan_world_states"][b], w32[0], g["plan_plans"][b], other_plans=scn.other_plans())
+        assert _same(r, g["obj_reward"][b]) and _same(gr, g["obj_grad"][b]) and _same(tr, g["obj_traj"][b])
 
 
 @pytest.mark.gpu
@@ -60,6 +80,9 @@ def test_hip_reproduces_golden(hip, name, kw, P, N):
     g = _load(name)
     scn = _scn(kw)
     eng = Engine(scn, "cuda:0")
+    leaf = _leaf(g)
+    if leaf:
+        eng.set_leaf_value(*leaf)
     ro = eng.rollout(g["init_states"], g["cand_weights_fp32"], want_traj=True)
     assert _same(ro["ctrl"], g["ctrl"]), "applied controls"
     assert _same(ro["traj"], g["traj"]), "trajectories"
@@ -69,3 +92,5 @@ def test_hip_reproduces_golden(hip, name, kw, P, N):
     assert np.array_equal(pl["best_init"], g["plan_best_init"]) and _same(pl["plans"], g["plan_plans"])
     feats, rew = eng.reward_batch(g["feat_world_states"], scn.designer_weights)
     assert _same(feats, g["feats"]) and _same(rew, g["rewards"])
+    ob = eng.mpc_reward_batch(g["plan_world_states"], g["cand_weights_fp32"][0], g["plan_plans"], want_traj=True)
+    assert _same(ob["reward"], g["obj_reward"]) and _same(ob["grad"], g["obj_grad"]) and _same(ob["traj"], g["obj_traj"])
