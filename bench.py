@@ -237,7 +237,7 @@ def main():
         valu = {"achieved": ach_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / VALU_PEAK_TFLOPS,
                 "algorithmic_flops_per_episode": flops,
                 "note": "at one wavefront per SIMD (2 048 episodes at H=10) a lone wavefront issues one instruction per "
-                        "~4.4 cycles: ~15 % of the vector peak is the ceiling of this batch size (DESIGN.md section 4)"}
+                        "~4.4 cycles: one instruction per algorithmic flop would give ~21 % of the vector peak at this batch size (DESIGN.md section 4)"}
         if pmc and pmc.get("sq_wave_cycles"):
             # quad-cycles in which a wavefront issued a VALU instruction / quad-cycles wavefronts were resident
             valu["issue_utilisation"] = pmc["sq_active_inst_valu"] / pmc["sq_wave_cycles"]
