@@ -111,7 +111,11 @@ mpc_kernel(const KernelParams p)
     const bool in_h = t < H;                                      // V_ROW: lanes H..15 of a row idle along
     const bool first = t == 0, last = t == H - 1;
     const unsigned long long first_mask = __ballot(first), last_mask = __ballot(last);
+#ifdef OCD_NO_ASM_CHAINS                                                      // ablation builds (tools/ablation.sh)
+    constexpr bool asm_chains = false;
+#else
     constexpr bool asm_chains = (V != V_LDS) && chain_supported<HT>::value;   // hand-scheduled recurrences (ocd_chains.h)
+#endif
     // trajectory slot inside the wavefront and control initialisation this lane works for
     const int slot = (V == V_SEG) ? (seg / K) : seg;
     const int kinit = (V == V_SEG) ? (seg - slot * K) : wave;
