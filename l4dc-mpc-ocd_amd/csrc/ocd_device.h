@@ -337,15 +337,20 @@ __device__ __forceinline__ LaneGradConst<L> lane_grad_const(const float (&w)[OCD
 //   collision ties (reduce_max over cars, merging.py:78): the cars a lane does not evaluate have
 //   col == 0 exactly, so the evaluated car is the maximum, tied with all others iff its own col is 0.
 // has_col / has_f (wave-uniform): some live lane is a collision / fence lane.
-template <int NO, int L, bool GRAD>
+// SUB = false: has_col / has_f are taken as true, the evaluation is one straight line.  A lone wavefront
+// pays ~2 issue slots for a branch it does not take and ~5-6 for one it takes (tools/microbench), and at
+// one wavefront per SIMD the launch lasts as long as its slowest wavefront, which has both kinds of lane
+// in nearly every pass: the skips only help where several wavefronts share a SIMD.
+template <int NO, int L, bool GRAD, bool SUB = true>
 __device__ __forceinline__ float reward_one(const ocd_scenario_desc &d, const float (&w)[OCD_MAX_FEATURES],
                                             float x, float y, float v, float sn, float cn,
                                             const BumpGeom (&bg)[NO > 0 ? NO : 1], const bool (&nc)[NO > 0 ? NO : 1],
-                                            const bool is_f, const bool has_col, const bool has_f, Q4 &q,
+                                            const bool is_f, const bool has_col_, const bool has_f_, Q4 &q,
                                             const PkConsts &pkc, const LaneGradConst<L> &lgc,
                                             const unsigned long long live_mask)
 {
     static_assert(L > 0 && NO > 0, "lane-feature reward only");
+    const bool has_col = SUB ? has_col_ : true, has_f = SUB ? has_f_ : true;
     const float tgt = d.target_speed;
     const float bound = 4.0f * (tgt * tgt);
     const float vel = v * sn;
@@ -455,14 +460,14 @@ __device__ __forceinline__ float reward_one(const ocd_scenario_desc &d, const fl
 #pragma unroll
     for (int l = 0; l < L; ++l) { tie[l] = pl[l] == pmin; ntie_min += tie[l] ? 1 : 0; }
     float qx = 0.0f;
-    if ((__ballot(ntie_min > 1) & live_mask) == 0ull) {
 #pragma unroll
-        for (int l = 0; l < L; ++l) {
-            const float g_r = (tie[l] ? lgc.g1[l] : lgc.g0[l]) * rl[l];
-            qx = qx + g_r * -1.0f;
-        }
-    } else {
+    for (int l = 0; l < L; ++l) {
+        const float g_r = (tie[l] ? lgc.g1[l] : lgc.g0[l]) * rl[l];
+        qx = qx + g_r * -1.0f;
+    }
+    if (__builtin_expect((__ballot(ntie_min > 1) & live_mask) != 0ull, 0)) {
         const float min_share = inv_count(ntie_min) * w_min;
+        qx = 0.0f;
 #pragma unroll
         for (int l = 0; l < L; ++l) {
             float gl = w[1 + l];

@@ -116,6 +116,11 @@ mpc_kernel(const KernelParams p)
 #else
     constexpr bool asm_chains = (V != V_LDS) && chain_supported<HT>::value;   // hand-scheduled recurrences (ocd_chains.h)
 #endif
+#ifdef OCD_SUB_SKIPS
+    constexpr bool latency_shape = false;
+#else
+    constexpr bool latency_shape = (V == V_ROW || V == V_SEG);   // chosen for <= ~1 wavefront per SIMD: straight-line reward_one
+#endif
     // trajectory slot inside the wavefront and control initialisation this lane works for
     const int slot = (V == V_SEG) ? (seg / K) : seg;
     const int kinit = (V == V_SEG) ? (seg - slot * K) : wave;
@@ -434,12 +439,14 @@ mpc_kernel(const KernelParams p)
                 }
                 const bool has_f = mf != 0ull, has_col = mc_any != 0ull;
                 OCD_STAMP(4);                              // choice of the evaluation
-                if (p.no_skips || multi != 0ull || (p.no_unify && (has_f || has_col))) {
+                if (__builtin_expect(p.no_skips || multi != 0ull || (p.no_unify && (has_f || has_col)), 0)) {
                     r = reward_state<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, true, true);
                     OCD_STAMP(5); OCD_STAMP_COUNT(12);     // every feature
-                } else if (has_f || has_col) {
-                    r = reward_one<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, nc, nf, has_col, has_f, q, pkc, lgc, feat_mask);
+                } else if (__builtin_expect(has_f || has_col, 1)) {
+                    r = reward_one<NO, L, GRAD, !latency_shape>(d, w, xn, yn, vn, sn, cn, bg, nc, nf, has_col, has_f, q, pkc, lgc, feat_mask);
                     OCD_STAMP(6); OCD_STAMP_COUNT(13);     // one feature per lane
+                    if (has_col) OCD_STAMP_COUNT(11);
+                    if (has_f) OCD_STAMP_COUNT(15);
                 } else {
                     r = reward_state<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, false, false);
                     OCD_STAMP(7); OCD_STAMP_COUNT(14);     // neither fence nor collision

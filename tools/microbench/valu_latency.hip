@@ -57,6 +57,23 @@ __global__ void bench(float *out, long long *cyc, int iters)
             asm volatile(REP64("v_pk_add_f32 %0, %0, %1\n") : "+v"(pa) : "v"(pm));
         } else if (MODE == 17) {  // pk_fma alternating with a plain fma on other registers
             asm volatile(REP64("v_pk_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %4, %5\n") : "+v"(pa), "+v"(b) : "v"(pk), "v"(pm), "v"(k), "v"(m));
+        } else if (MODE == 18) {  // fma + taken s_branch to the next instruction (per pair)
+            asm volatile(REP64("v_fma_f32 %0, %0, %1, %2\n s_branch 1f\n1:\n") : "+v"(a) : "v"(k), "v"(m));
+        } else if (MODE == 19) {  // fma + never-taken conditional branch (per pair)
+            asm volatile("s_cmp_eq_u32 0, 1\n" REP64("v_fma_f32 %0, %0, %1, %2\n s_cbranch_scc1 1f\n1:\n") : "+v"(a) : "v"(k), "v"(m) : "scc");
+        } else if (MODE == 20) {  // 4 fma + taken branch (per group of 5)
+            asm volatile(REP64("v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n s_branch 1f\n1:\n") : "+v"(a) : "v"(k), "v"(m));
+        } else if (MODE == 21) {  // fma + taken conditional branch over 8 skipped instructions (per pair)
+            asm volatile("s_cmp_eq_u32 0, 0\n" REP64("v_fma_f32 %0, %0, %1, %2\n s_cbranch_scc1 1f\n v_mov_b32 %0, 0\n v_mov_b32 %0, 0\n v_mov_b32 %0, 0\n v_mov_b32 %0, 0\n v_mov_b32 %0, 0\n v_mov_b32 %0, 0\n v_mov_b32 %0, 0\n v_mov_b32 %0, 0\n1:\n") : "+v"(a) : "v"(k), "v"(m) : "scc");
+        } else if (MODE == 22) {  // v_cmp -> SGPR pair, s_nop, v_cndmask on it (per triple)
+            asm volatile(REP64("v_cmp_gt_f32 s[20:21], %0, %1\n s_nop 1\n v_cndmask_b32 %0, %0, %2, s[20:21]\n") : "+v"(a) : "v"(m), "v"(k) : "s20", "s21");
+        } else if (MODE == 23) {  // v_cmp -> vcc, v_cndmask on vcc (per pair)
+            asm volatile(REP64("v_cmp_gt_f32 vcc, %0, %1\n s_nop 1\n v_cndmask_b32 %0, %0, %2, vcc\n") : "+v"(a) : "v"(m), "v"(k) : "vcc");
+        } else if (MODE == 24) {  // v_exp_f32 dependent
+            asm volatile(REP64("v_exp_f32 %0, %0\n") : "+v"(a));
+        } else if (MODE == 25) {  // v_readlane + v_writelane round trip
+            int sreg;
+            asm volatile(REP64("v_readlane_b32 %1, %0, 3\n s_nop 3\n v_writelane_b32 %0, %1, 5\n") : "+v"(a), "=s"(sreg));
         } else if (MODE == 13) {  // ds_bpermute dependent chain
 #pragma unroll
             for (int j = 0; j < 64; ++j) a = __int_as_float(__builtin_amdgcn_ds_bpermute(((threadIdx.x + 1) & 63) << 2, __float_as_int(a)));
@@ -129,6 +146,14 @@ int main()
         run<15>("dependent v_pk_mul_f32", 64, waves);
         run<16>("dependent v_pk_add_f32", 64, waves);
         run<17>("pk_fma + fma alternating (per pair)", 64, waves);
+        run<18>("fma + taken s_branch (per pair)", 64, waves);
+        run<19>("fma + untaken s_cbranch (per pair)", 64, waves);
+        run<20>("4 fma + taken s_branch (per group)", 64, waves);
+        run<21>("fma + taken s_cbranch over 8 instrs (per pair)", 64, waves);
+        run<22>("v_cmp->sgpr, s_nop 1, v_cndmask (per triple)", 64, waves);
+        run<23>("v_cmp->vcc, s_nop 1, v_cndmask (per triple)", 64, waves);
+        run<24>("dependent v_exp_f32", 64, waves);
+        run<25>("readlane, s_nop 3, writelane (per triple)", 64, waves);
     }
     return 0;
 }

@@ -14,8 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 SECTIONS = ["outside the passes", "v/heading recurrence", "own step + sincos", "x/y recurrence",
             "evaluation choice (ballots)", "features: everything", "features: one per lane", "features: none active",
-            "x/y adjoint recurrence", "Jacobian + v/heading adjoint rec.", "control update", "-",
-            "#passes everything", "#passes one-per-lane", "#passes none", "-"]
+            "x/y adjoint recurrence", "Jacobian + v/heading adjoint rec.", "control update", "#one-per-lane passes with a collision lane",
+            "#passes everything", "#passes one-per-lane", "#passes none", "#one-per-lane passes with a fence lane"]
 
 
 def main():
