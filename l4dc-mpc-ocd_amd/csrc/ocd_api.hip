@@ -149,6 +149,8 @@ void base_params(const ocd_scenario *scn, ocd::KernelParams &p)
     p.no_skips = scn->opt_no_skips;
     p.scan_mode = scn->opt_scan_mode;
     p.no_unify = scn->opt_no_unify;
+    p.force_full = scn->opt_no_skips ? ~0ull : 0ull;
+    p.force_full_any = scn->opt_no_unify ? ~0ull : 0ull;
     p.reset_phase = scn->opt_reset_phase;
     p.chunk_size = scn->opt_chunk;
 }

@@ -218,6 +218,7 @@ mpc_kernel(const KernelParams p)
     // lanes whose reward features count (the last horizon step is scored by the terminal value instead)
     const bool feat_live = live && !(has_leaf && last);
     const unsigned long long feat_mask = __ballot(feat_live);
+    const unsigned long long force_full = p.force_full, force_full_any = p.force_full_any;
 
     if (p.mode == OCD_MODE_ROLLOUT && p.traj_out && writer) {
         float *tr = p.traj_out + (size_t)prob * (T + 1) * (NO + 1) * 4;
@@ -428,25 +429,31 @@ mpc_kernel(const KernelParams p)
                 bool nc[NOA];
                 nc[0] = false;
                 const bool nf = needs_fence(d, xn);
-                unsigned long long mf = __ballot(nf) & feat_mask, mc_any = 0ull, multi = 0ull;
+                unsigned long long mf = __builtin_amdgcn_ballot_w64(nf) & feat_mask, mc_any = 0ull, multi = 0ull;
 #pragma unroll
                 for (int j = 0; j < NO; ++j) {
                     const float dx = xn - bg[j].cx, dy = yn - bg[j].cy;
-                    nc[j] = (__builtin_fabsf(dx) < wx1[j]) && (__builtin_fabsf(dy) < wy1[j]);
-                    const unsigned long long mj = __ballot(nc[j]) & feat_mask;
+                    const bool ncx = __builtin_fabsf(dx) < wx1[j], ncy = __builtin_fabsf(dy) < wy1[j];
+                    nc[j] = ncx && ncy;
+                    const unsigned long long mj = __builtin_amdgcn_ballot_w64(ncx) & __builtin_amdgcn_ballot_w64(ncy) & feat_mask;
                     multi |= (mj & (mf | mc_any));
                     mc_any |= mj;
                 }
                 const bool has_f = mf != 0ull, has_col = mc_any != 0ull;
+                const unsigned long long any_feat = mf | mc_any;
                 OCD_STAMP(4);                              // choice of the evaluation
-                if (__builtin_expect(p.no_skips || multi != 0ull || (p.no_unify && (has_f || has_col)), 0)) {
-                    r = reward_state<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, true, true);
-                    OCD_STAMP(5); OCD_STAMP_COUNT(12);     // every feature
-                } else if (__builtin_expect(has_f || has_col, 1)) {
-                    r = reward_one<NO, L, GRAD, !latency_shape>(d, w, xn, yn, vn, sn, cn, bg, nc, nf, has_col, has_f, q, pkc, lgc, feat_mask);
-                    OCD_STAMP(6); OCD_STAMP_COUNT(13);     // one feature per lane
-                    if (has_col) OCD_STAMP_COUNT(11);
-                    if (has_f) OCD_STAMP_COUNT(15);
+                // (the diagnostics knobs enter as two wave-uniform masks: two scalar tests decide the path)
+                const unsigned long long full_m = multi | force_full | (any_feat & force_full_any);
+                if (__builtin_expect((any_feat | force_full) != 0ull, 1)) {
+                    if (__builtin_expect(full_m != 0ull, 0)) {
+                        r = reward_state<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, true, true);
+                        OCD_STAMP(5); OCD_STAMP_COUNT(12);     // every feature
+                    } else {
+                        r = reward_one<NO, L, GRAD, !latency_shape>(d, w, xn, yn, vn, sn, cn, bg, nc, nf, has_col, has_f, q, pkc, lgc, feat_mask);
+                        OCD_STAMP(6); OCD_STAMP_COUNT(13);     // one feature per lane
+                        if (has_col) OCD_STAMP_COUNT(11);
+                        if (has_f) OCD_STAMP_COUNT(15);
+                    }
                 } else {
                     r = reward_state<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, false, false);
                     OCD_STAMP(7); OCD_STAMP_COUNT(14);     // neither fence nor collision
