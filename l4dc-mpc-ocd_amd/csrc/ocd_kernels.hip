@@ -507,7 +507,9 @@ mpc_kernel(const KernelParams p)
                 float Lx = 0.0f, Ly = 0.0f;
                 if (V == V_ROW) {
                     // idle lanes (t >= H) contribute nothing to the adjoints flowing down the row
-                    if (!in_h) { q.qx = 0.0f; q.qy = 0.0f; q.qv = 0.0f; q.qth = 0.0f; }
+                    // (selects, not a divergent branch: a branch costs a lone wavefront 2-6 issue slots)
+                    q.qx = in_h ? q.qx : 0.0f; q.qy = in_h ? q.qy : 0.0f;
+                    q.qv = in_h ? q.qv : 0.0f; q.qth = in_h ? q.qth : 0.0f;
                     const float qx_a = row_above(0.0f, q.qx); // adjoint term of the step above (0 for the top lane)
                     const float qy_a = row_above(0.0f, q.qy);
 #pragma unroll
