@@ -146,7 +146,9 @@ void ocd_scenario_destroy(ocd_scenario *scn);
  *   "chunk_size": horizon steps per lane of scan_mode 4 (0 = automatic among the compiled sizes);
  *   "no_unified_features": 1 = never evaluate a lane's single active feature through the shared path;
  *   "no_feature_skips": 1 = evaluate the collision and fence features even where they are provably
- *                       zero (diagnostics; default 0).
+ *                       zero (diagnostics; default 0);
+ *   "no_latency_build": 1 = never pick the branch-free builds of scan modes 2 / 3 that launches with at
+ *                       most one wavefront per SIMD use (diagnostics; default 0).
  * Episode bookkeeping:
  *   "reset_phase": world.reset() calls made before episode 0 of the next ocd_rollout_episodes batch
  *                  (see ocd_scenario_desc.teleport_period); default 0. */

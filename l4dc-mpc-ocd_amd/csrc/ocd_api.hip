@@ -24,7 +24,7 @@ struct ocd_scenario {
     int32_t K;
     int32_t D;
     // per-handle options (ocd_scenario_set_option)
-    int32_t opt_segs = 0, opt_no_skips = 0, opt_scan_mode = 0, opt_no_unify = 0, opt_reset_phase = 0, opt_chunk = 0;
+    int32_t opt_segs = 0, opt_no_skips = 0, opt_scan_mode = 0, opt_no_unify = 0, opt_reset_phase = 0, opt_chunk = 0, opt_no_lat = 0;
     // The planner's fixed view of the scripted cars' plans (planner_car.py:58-80:
     // plan[j] from index 0, then the assumed default) is a scenario constant; rollouts
     // read it from a small device buffer owned by the handle, one per device.
@@ -151,6 +151,7 @@ void base_params(const ocd_scenario *scn, ocd::KernelParams &p)
     p.no_unify = scn->opt_no_unify;
     p.force_full = scn->opt_no_skips ? ~0ull : 0ull;
     p.force_full_any = scn->opt_no_unify ? ~0ull : 0ull;
+    p.no_latency_build = scn->opt_no_lat;
     p.reset_phase = scn->opt_reset_phase;
     p.chunk_size = scn->opt_chunk;
 }
@@ -208,6 +209,7 @@ int32_t ocd_scenario_set_option(ocd_scenario *scn, const char *name, int32_t val
         return OCD_OK;
     }
     if (std::strcmp(name, "no_unified_features") == 0) { scn->opt_no_unify = value ? 1 : 0; return OCD_OK; }
+    if (std::strcmp(name, "no_latency_build") == 0) { scn->opt_no_lat = value ? 1 : 0; return OCD_OK; }
     if (std::strcmp(name, "no_feature_skips") == 0) { scn->opt_no_skips = value ? 1 : 0; return OCD_OK; }
     if (std::strcmp(name, "reset_phase") == 0) {
         if (value < 0) return fail(OCD_ERR_INVALID_ARG, "reset_phase %d < 0", value);

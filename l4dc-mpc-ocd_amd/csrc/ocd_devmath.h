@@ -96,7 +96,7 @@ __device__ __forceinline__ v2f splat2(float v) { return v2f{v, v}; }
 __device__ __forceinline__ v2f div2_(v2f n, v2f d)
 {
     bool f0, f1, g0, g1;
-    v2f ds, ns, r, e, q;
+    v2f ds, ns, r, r1, e, q;
     ds.x = __builtin_amdgcn_div_scalef(n.x, d.x, false, &g0);
     ds.y = __builtin_amdgcn_div_scalef(n.y, d.y, false, &g1);
     ns.x = __builtin_amdgcn_div_scalef(n.x, d.x, true, &f0);
@@ -106,15 +106,16 @@ __device__ __forceinline__ v2f div2_(v2f n, v2f d)
     // s_nop 0: a v_rcp_f32 result needs one wait state before a non-transcendental instruction reads it
     asm("s_nop 0\n"
         "v_pk_fma_f32 %[e], %[ds], %[r], 1.0 op_sel_hi:[1,1,0] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"   // 1 - ds*r
-        "v_pk_fma_f32 %[r], %[e], %[r], %[r]\n"                                                  // refined reciprocal
-        "v_pk_mul_f32 %[q], %[ns], %[r]\n"
+        "v_pk_fma_f32 %[r1], %[e], %[r], %[r]\n"                                                 // refined reciprocal
+        "v_pk_mul_f32 %[q], %[ns], %[r1]\n"
         "v_pk_fma_f32 %[e], %[ds], %[q], %[ns] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
-        "v_pk_fma_f32 %[q], %[e], %[r], %[q]\n"
+        "v_pk_fma_f32 %[q], %[e], %[r1], %[q]\n"
         "v_pk_fma_f32 %[e], %[ds], %[q], %[ns] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
-        : [e] "=&v"(e), [r] "+v"(r), [q] "=&v"(q) : [ds] "v"(ds), [ns] "v"(ns));
+        // (r1 is its own output: a tied in/out operand costs a v_mov_b64 of the two v_rcp results)
+        : [e] "=&v"(e), [r1] "=&v"(r1), [q] "=&v"(q) : [ds] "v"(ds), [ns] "v"(ns), [r] "v"(r));
     v2f out;
-    out.x = __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(e.x, r.x, q.x, f0), d.x, n.x);
-    out.y = __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(e.y, r.y, q.y, f1), d.y, n.y);
+    out.x = __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(e.x, r1.x, q.x, f0), d.x, n.x);
+    out.y = __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(e.y, r1.y, q.y, f1), d.y, n.y);
     return out;
 }
 

@@ -62,6 +62,7 @@ struct KernelParams {
     int32_t no_unify;          // diagnostics: 1 = never use the one-feature-per-lane evaluation
     // the two knobs as lane masks (all ones / zero), so the kernels test them with plain scalar and/or
     unsigned long long force_full, force_full_any;
+    int32_t no_latency_build;  // diagnostics: 1 = never pick the LAT builds of V_ROW / V_SEG
     int32_t chunk_size;        // V_CHUNK: 0 = pick the compiled chunk size by cost, else force this one
     int32_t n_cus;             // compute units of the device (launch shape heuristics)
     unsigned long long *debug; // diagnostic builds only (OCD_STAMPS): per-wavefront cycle totals, else nullptr

@@ -87,10 +87,17 @@ __host__ __device__ constexpr Geo geo_lds(int H)
 
 // ---------------------------------------------------------------- the kernel
 // LEAF: the terminal-value lookup (leaf_evaluation) is compiled into the generic kernel only.
-template <int HT, int NO, int L, int V, bool LEAF = false>
+// LAT (V_ROW / V_SEG): the launch puts at most one wavefront on a SIMD, so it lasts as long as its slowest
+//   wavefront, and a lone wavefront pays 2 issue slots for every branch it does not take, ~6 for one it
+//   takes (tools/microbench/valu_latency.hip).  The slowest wavefront has a fence or collision lane in
+//   nearly every pass, so this build evaluates reward_one unconditionally and straight-line (no "none
+//   active" path, no has_col / has_f skips) and repairs the rare pass with a multi-feature lane afterwards.
+//   The diagnostics knobs no_feature_skips / no_unified_features select the LAT = false build.
+template <int HT, int NO, int L, int V, bool LEAF = false, bool LAT = false>
 __global__ void __launch_bounds__(V == V_SEG ? 64 : 64 * OCD_MAX_CTRL_INITS)
 mpc_kernel(const KernelParams p)
 {
+    static_assert(!LAT || V == V_ROW || V == V_SEG, "LAT is a V_ROW / V_SEG build");
     static_assert(HT > 0 || V == V_LDS, "the generic (run-time H) kernel exchanges through LDS");
     static_assert(!LEAF || HT == 0, "the terminal value runs in the generic kernel");
     static_assert(V != V_ROW || HT <= 16, "V_ROW keeps a trajectory inside one 16-lane DPP row");
@@ -115,11 +122,6 @@ mpc_kernel(const KernelParams p)
     constexpr bool asm_chains = false;
 #else
     constexpr bool asm_chains = (V != V_LDS) && chain_supported<HT>::value;   // hand-scheduled recurrences (ocd_chains.h)
-#endif
-#ifdef OCD_SUB_SKIPS
-    constexpr bool latency_shape = false;
-#else
-    constexpr bool latency_shape = (V == V_ROW || V == V_SEG);   // chosen for <= ~1 wavefront per SIMD: straight-line reward_one
 #endif
     // trajectory slot inside the wavefront and control initialisation this lane works for
     const int slot = (V == V_SEG) ? (seg / K) : seg;
@@ -442,21 +444,30 @@ mpc_kernel(const KernelParams p)
                 const bool has_f = mf != 0ull, has_col = mc_any != 0ull;
                 const unsigned long long any_feat = mf | mc_any;
                 OCD_STAMP(4);                              // choice of the evaluation
-                // (the diagnostics knobs enter as two wave-uniform masks: two scalar tests decide the path)
-                const unsigned long long full_m = multi | force_full | (any_feat & force_full_any);
-                if (__builtin_expect((any_feat | force_full) != 0ull, 1)) {
-                    if (__builtin_expect(full_m != 0ull, 0)) {
+                if constexpr (LAT) {
+                    r = reward_one<NO, L, GRAD, false>(d, w, xn, yn, vn, sn, cn, bg, nc, nf, true, true, q, pkc, lgc, feat_mask);
+                    OCD_STAMP(6); OCD_STAMP_COUNT(13);     // one feature per lane
+                    if (__builtin_expect(multi != 0ull, 0)) {
                         r = reward_state<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, true, true);
-                        OCD_STAMP(5); OCD_STAMP_COUNT(12);     // every feature
-                    } else {
-                        r = reward_one<NO, L, GRAD, !latency_shape>(d, w, xn, yn, vn, sn, cn, bg, nc, nf, has_col, has_f, q, pkc, lgc, feat_mask);
-                        OCD_STAMP(6); OCD_STAMP_COUNT(13);     // one feature per lane
-                        if (has_col) OCD_STAMP_COUNT(11);
-                        if (has_f) OCD_STAMP_COUNT(15);
+                        OCD_STAMP(5); OCD_STAMP_COUNT(12); // every feature
                     }
                 } else {
-                    r = reward_state<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, false, false);
-                    OCD_STAMP(7); OCD_STAMP_COUNT(14);     // neither fence nor collision
+                    // (the diagnostics knobs enter as two wave-uniform masks: two scalar tests decide the path)
+                    const unsigned long long full_m = multi | force_full | (any_feat & force_full_any);
+                    if (__builtin_expect((any_feat | force_full) != 0ull, 1)) {
+                        if (__builtin_expect(full_m != 0ull, 0)) {
+                            r = reward_state<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, true, true);
+                            OCD_STAMP(5); OCD_STAMP_COUNT(12);     // every feature
+                        } else {
+                            r = reward_one<NO, L, GRAD, true>(d, w, xn, yn, vn, sn, cn, bg, nc, nf, has_col, has_f, q, pkc, lgc, feat_mask);
+                            OCD_STAMP(6); OCD_STAMP_COUNT(13);     // one feature per lane
+                            if (has_col) OCD_STAMP_COUNT(11);
+                            if (has_f) OCD_STAMP_COUNT(15);
+                        }
+                    } else {
+                        r = reward_state<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, false, false);
+                        OCD_STAMP(7); OCD_STAMP_COUNT(14);     // neither fence nor collision
+                    }
                 }
             } else {
                 r = reward_state<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr);
@@ -915,14 +926,22 @@ static hipError_t launch_mpc(const KernelParams &p_in, hipStream_t st)
     else segs = p.segs_used > 0 ? clampi(p.segs_used, 1, G.SEGS) : clampi(ceil_div(n, cus), 1, G.SEGS);
     p.segs_used = segs;
     const unsigned blocks = (unsigned)ceil_div(n, segs);
+    // LAT builds: lane features, at most one wavefront per SIMD, no diagnostics knob set
+    const bool lat = L > 0 && NO > 0 && !p.no_skips && !p.no_unify && !p.no_latency_build;
     if constexpr (HT > 0) {
         if (variant == V_SEG) {
-            if constexpr (HT * 3 <= 64) hipLaunchKernelGGL((mpc_kernel<HT, NO, L, V_SEG>), dim3(blocks), dim3(64), 0, st, p);
+            if constexpr (HT * 3 <= 64) {
+                if (lat && blocks <= simds) hipLaunchKernelGGL((mpc_kernel<HT, NO, L, V_SEG, false, true>), dim3(blocks), dim3(64), 0, st, p);
+                else hipLaunchKernelGGL((mpc_kernel<HT, NO, L, V_SEG>), dim3(blocks), dim3(64), 0, st, p);
+            }
             return hipGetLastError();
         }
         if (variant == V_ROW) {
             const size_t lds = (size_t)2 * K * G.SEL_FLOATS * sizeof(float);
-            if constexpr (HT <= 16) hipLaunchKernelGGL((mpc_kernel<HT, NO, L, V_ROW>), dim3(blocks), dim3(64 * K), lds, st, p);
+            if constexpr (HT <= 16) {
+                if (lat && (long long)blocks * K <= simds) hipLaunchKernelGGL((mpc_kernel<HT, NO, L, V_ROW, false, true>), dim3(blocks), dim3(64 * K), lds, st, p);
+                else hipLaunchKernelGGL((mpc_kernel<HT, NO, L, V_ROW>), dim3(blocks), dim3(64 * K), lds, st, p);
+            }
             return hipGetLastError();
         }
     }

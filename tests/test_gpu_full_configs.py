@@ -35,6 +35,9 @@ def test_config3_every_episode_bitwise(hip, oracle, scan_mode):
     eng.set_option("scan_mode", scan_mode)
     got = eng.rollout(inits, w32)["returns"]
     assert got.shape == (64 * 32,) and np.array_equal(got, ref)
+    if scan_mode in (0, 2, 3):                          # one wavefront per SIMD picks the LAT build: the other one too
+        eng.set_option("no_latency_build", 1)
+        assert np.array_equal(eng.rollout(inits, w32)["returns"], ref)
 
 
 @pytest.mark.parametrize("cfg,n_sampled_ranges", [(4, 40), (5, 40)])

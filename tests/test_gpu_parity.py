@@ -179,10 +179,15 @@ def test_all_scan_variants_bitwise(oracle, eng_factory, hip, scan_mode, name, H,
         ro = eng.rollout(inits, w[:2], want_traj=True)
         eng.set_option("segs_per_wave", 3)          # several trajectories per wavefront as well
         out3 = eng.plan_batch(ws, w, want_all=True)
+        eng.set_option("no_latency_build", 1)       # the throughput builds of the DPP variants (small launches pick LAT)
+        out4 = eng.plan_batch(ws, w, want_all=True)
+        ro4 = eng.rollout(inits, w[:2], want_traj=True)
     finally:
         eng.set_option("scan_mode", 0)
         eng.set_option("segs_per_wave", 0)
-    for o in (out, out3):
+        eng.set_option("no_latency_build", 0)
+    assert_bitwise(ro4["traj"], rr["traj"], "traj"); assert_bitwise(ro4["returns"], rr["returns"], "returns")
+    for o in (out, out3, out4):
         assert_bitwise(o["all_losses"], ref["all_losses"], "losses"); assert_bitwise(o["all_plans"], ref["all_plans"], "plans")
         assert np.array_equal(o["best_init"], ref["best_init"]); assert_bitwise(o["best_loss"], ref["best_loss"], "best loss")
     assert_bitwise(ro["ctrl"], rr["ctrl"], "controls"); assert_bitwise(ro["traj"], rr["traj"], "traj")
@@ -235,11 +240,13 @@ def test_non_finite_trajectories_bitwise(oracle, eng_factory, hip, segs, mode):
     assert np.isinf(ref["all_losses"]).any() or np.isnan(ref["all_losses"]).any()
     eng.set_option("segs_per_wave", segs)
     eng.set_option("scan_mode", mode)
+    eng.set_option("no_latency_build", segs % 2)       # both builds of the DPP variants
     try:
         out = eng.plan_batch(ws, w, want_all=True)
         ro = eng.rollout_from_state(ws, w, first_step=0, n_steps=8)
     finally:
         eng.set_option("segs_per_wave", 0)
+        eng.set_option("no_latency_build", 0)
     assert_bitwise(out["all_losses"], ref["all_losses"], "losses")
     assert_bitwise(out["all_plans"], ref["all_plans"], "plans")
     assert np.array_equal(out["best_init"], ref["best_init"])

@@ -79,6 +79,7 @@ def test_random_descriptor_bitwise(hip, oracle, case):
     eng.set_option("scan_mode", int(rng.integers(0, 5)))            # any variant the shape allows
     phase = int(rng.integers(0, 3))
     eng.set_option("reset_phase", phase)
+    eng.set_option("no_latency_build", case % 2)                    # latency and throughput builds of the DPP variants
     B = int(rng.integers(1, 12))
     ws = np.zeros((B, NO + 1, 4), dtype=np.float32)
     ws[:, 0, 0] = rng.uniform(-0.2, 0.2, B); ws[:, 0, 1] = rng.uniform(-1.4, -0.5, B)

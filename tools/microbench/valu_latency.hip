@@ -74,6 +74,20 @@ __global__ void bench(float *out, long long *cyc, int iters)
         } else if (MODE == 25) {  // v_readlane + v_writelane round trip
             int sreg;
             asm volatile(REP64("v_readlane_b32 %1, %0, 3\n s_nop 3\n v_writelane_b32 %0, %1, 5\n") : "+v"(a), "=s"(sreg));
+        } else if (MODE == 26) {  // v_cmp -> SGPR, dependent s_and on it, v_cndmask on the s_and result (per triple)
+            asm volatile(REP64("v_cmp_gt_f32 s[20:21], %0, %1\n s_and_b64 s[22:23], s[20:21], exec\n s_nop 0\n v_cndmask_b32 %0, %0, %2, s[22:23]\n") : "+v"(a) : "v"(m), "v"(k) : "s20", "s21", "s22", "s23");
+        } else if (MODE == 27) {  // same instruction mix, the s_and independent of the v_cmp
+            asm volatile(REP64("v_cmp_gt_f32 s[20:21], %0, %1\n s_and_b64 s[22:23], s[24:25], exec\n s_nop 0\n v_cndmask_b32 %0, %0, %2, s[20:21]\n") : "+v"(a) : "v"(m), "v"(k) : "s20", "s21", "s22", "s23", "s24", "s25");
+        } else if (MODE == 28) {  // div_scale flag -> SGPR, s_mov to vcc, div_fmas (per triple + nops)
+            asm volatile(REP64("v_div_scale_f32 %1, s[20:21], %0, %2, %0\n s_mov_b64 vcc, s[20:21]\n s_nop 3\n v_div_fmas_f32 %0, %1, %2, %0\n") : "+v"(a), "+v"(b) : "v"(k) : "s20", "s21", "vcc");
+        } else if (MODE == 29) {  // div_scale flag -> vcc directly, div_fmas
+            asm volatile(REP64("v_div_scale_f32 %1, vcc, %0, %2, %0\n s_nop 3\n v_div_fmas_f32 %0, %1, %2, %0\n") : "+v"(a), "+v"(b) : "v"(k) : "vcc");
+        } else if (MODE == 30) {  // s_mov vcc then cndmask_dpp on it (SALU -> VALU)
+            asm volatile(REP64("s_mov_b64 vcc, s[20:21]\n v_cndmask_b32 %0, %0, %1, vcc\n") : "+v"(a) : "v"(m) : "s20", "s21", "vcc");
+        } else if (MODE == 31) {  // v_cmp -> vcc, s_cbranch_vccz untaken (per pair)
+            asm volatile(REP64("v_cmp_gt_f32 vcc, %0, %0\n s_cbranch_vccnz 1f\n1:\n") : "+v"(a) : : "vcc");
+        } else if (MODE == 32) {  // v_cmp -> sgpr, s_cmp on it, s_cbranch_scc untaken (per triple)
+            asm volatile(REP64("v_cmp_gt_f32 s[20:21], %0, %0\n s_cmp_lg_u64 s[20:21], 0\n s_cbranch_scc1 1f\n1:\n") : "+v"(a) : : "s20", "s21", "scc");
         } else if (MODE == 13) {  // ds_bpermute dependent chain
 #pragma unroll
             for (int j = 0; j < 64; ++j) a = __int_as_float(__builtin_amdgcn_ds_bpermute(((threadIdx.x + 1) & 63) << 2, __float_as_int(a)));
@@ -154,6 +168,13 @@ int main()
         run<23>("v_cmp->vcc, s_nop 1, v_cndmask (per triple)", 64, waves);
         run<24>("dependent v_exp_f32", 64, waves);
         run<25>("readlane, s_nop 3, writelane (per triple)", 64, waves);
+        run<26>("v_cmp->sgpr, dep. s_and, nop, cndmask (per 4)", 64, waves);
+        run<27>("v_cmp->sgpr, indep. s_and, nop, cndmask (per 4)", 64, waves);
+        run<28>("div_scale->sgpr, s_mov vcc, nop3, div_fmas (per 4)", 64, waves);
+        run<29>("div_scale->vcc, nop3, div_fmas (per 3)", 64, waves);
+        run<30>("s_mov vcc, v_cndmask (per pair)", 64, waves);
+        run<31>("v_cmp->vcc, untaken s_cbranch_vccnz (per pair)", 64, waves);
+        run<32>("v_cmp->sgpr, s_cmp, untaken s_cbranch_scc1 (per 3)", 64, waves);
     }
     return 0;
 }

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="chunk_size option (scan mode 4)")
     ap.add_argument("--no-skips", type=int, default=0)
     ap.add_argument("--no-unify", type=int, default=0)
+    ap.add_argument("--no-lat", type=int, default=0)
     ap.add_argument("--scan-mode", default="0", help="comma list of scan modes: 0 auto, 1 LDS windows, 2 DPP rows, 3 all inits in one wavefront")
     a = ap.parse_args()
     import torch
@@ -39,6 +40,7 @@ def main():
         eng.set_option("no_feature_skips", a.no_skips)
         eng.set_option("chunk_size", a.chunk)
         eng.set_option("no_unified_features", a.no_unify)
+        eng.set_option("no_latency_build", a.no_lat)
         for mode in [int(m) for m in a.scan_mode.split(",")]:
             if (mode == 2 and c["horizon"] > 16) or (mode == 3 and scn.desc.n_ctrl_inits * c["horizon"] > 64) or \
                     (mode == 4 and c["horizon"] % 5):
