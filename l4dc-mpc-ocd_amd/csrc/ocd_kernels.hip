@@ -622,7 +622,13 @@ mpc_kernel(const KernelParams p)
         };
 
         const int n_iter = d.n_iter;
-        for (int it = 0; it < n_iter; ++it) horizon_pass(bool_c<true>{});
+        if constexpr (LAT) {                              // two passes per taken back-edge
+            int it = 0;
+            for (; it + 1 < n_iter; it += 2) { horizon_pass(bool_c<true>{}); horizon_pass(bool_c<true>{}); }
+            if (it < n_iter) horizon_pass(bool_c<true>{});
+        } else {
+            for (int it = 0; it < n_iter; ++it) horizon_pass(bool_c<true>{});
+        }
         horizon_pass(bool_c<false>{});
 
         // the objective's horizon sum is complete in every lane (V_LDS) or in lane H-1 (V_ROW, V_SEG)
