@@ -187,8 +187,9 @@ __device__ __forceinline__ void sincos_(float x, float &s_out, float &c_out)
     const int32_t q = (int32_t)n;
     const float sv = (q & 1) ? cr : sr;
     const float cv = (q & 1) ? sr : cr;
-    s_out = (q & 2) ? -sv : sv;
-    c_out = ((q + 1) & 2) ? -cv : cv;
+    // quadrant signs as a sign-bit xor (exact negation): no compare, so no mask hazard slots
+    s_out = __uint_as_float(__float_as_uint(sv) ^ (((uint32_t)q << 30) & 0x80000000u));
+    c_out = __uint_as_float(__float_as_uint(cv) ^ (((uint32_t)(q + 1) << 30) & 0x80000000u));
 }
 
 } // namespace ocd
