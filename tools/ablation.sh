@@ -3,7 +3,8 @@
 #   build the arms HERE (no GPU needed):   bash tools/ablation.sh build
 #   time them on the GPU box:              bash tools/ablation.sh run     (prints ms per launch, configs 2 and 3)
 # Arms: shipped library; -DOCD_NO_PACKED (scalar division / exp cores); -DOCD_NO_ASM_CHAINS (compiler-scheduled
-# DPP recurrences); both; and the shipped library with the diagnostics knobs no_unified_features / no_feature_skips.
+# DPP recurrences); both; and the shipped library with the diagnostics knobs no_unified_features / no_feature_skips /
+# no_latency_build (the knobs other than no_latency_build also select the non-LAT builds).
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 CSRC=$ROOT/l4dc-mpc-ocd_amd/csrc
@@ -26,6 +27,8 @@ else
     python tools/sweep.py --configs 2,3 --scan-mode 0 --segs 0 --reps 10 --no-unify 1 2>&1 | grep cfg
     echo "== libocd_hip.so, no_feature_skips"
     python tools/sweep.py --configs 2,3 --scan-mode 0 --segs 0 --reps 10 --no-skips 1 2>&1 | grep cfg
+    echo "== libocd_hip.so, no_latency_build (V_ROW / V_SEG with the none-active path and the has_col / has_f skips)"
+    python tools/sweep.py --configs 2,3 --scan-mode 0 --segs 0 --reps 10 --no-lat 1 2>&1 | grep cfg
     echo "== libocd_hip.so again"
     python tools/sweep.py --configs 2,3 --scan-mode 0 --segs 0 --reps 10 2>&1 | grep cfg
 fi
