@@ -63,8 +63,7 @@ class CMAES:
                   + self.c1 * (np.outer(self.pc, self.pc) + (1 - hsig) * self.cc * (2 - self.cc) * self.C)
                   + self.cmu * rank_mu)
         self.sigma *= np.exp((self.cs / self.damps) * (np.linalg.norm(self.ps) / self.chiN - 1))
-        self.C = np.triu(self.C) + np.triu(self.C, 1).T
-        ev, self.B = np.linalg.eigh(self.C)
+        ev, self.B = np.linalg.eigh(self.C)                         # reads the lower triangle only
         self.Dg = np.sqrt(np.maximum(ev, 1e-20))
         self.invsqrtC = (self.B / self.Dg) @ self.B.T
         self.gen += 1

@@ -15,7 +15,7 @@ from .. import experiments  # noqa: F401
 from ..experiments._sampling import make_get_init_state
 from .._describe import describe, engine_for
 from ... import sharding
-from ...scenarios import planner_weights_fp32, planner_weights_fp32_batch
+from ...scenarios import planner_weights_fp32, planner_weights_fp32_batch, row_dots
 
 
 class list2(list):  # mutable list that can carry a .seed attribute (mpc_ord.py:10-12)
@@ -70,21 +70,41 @@ class MPC_ORD:
                         designer_weights=self.designer_weights)
         return engine_for(desc)
 
-    def _returns(self, inits, weights_2d):
-        """fp32 sample rewards [P, N, S] of every (candidate, init, sample) episode; sharded when distributed."""
+    def _init_states_dev(self, eng, init):
+        """Device copy of the init states, re-uploaded only when they change (they are the same every generation)."""
+        import torch
+        key = (str(eng.device), init.tobytes())
+        if getattr(self, "_init_dev_key", None) != key:
+            self._init_dev = torch.as_tensor(init).to(eng.device)
+            self._init_dev_key = key
+        return self._init_dev
+
+    def _returns(self, inits, weights_2d, while_running=None):
+        """fp32 sample rewards [P, N, S] of every (candidate, init, sample) episode; sharded when distributed.
+        `while_running()` (host bookkeeping that does not need the returns) runs between launch and readback."""
         import torch
         import torch.distributed as dist
         eng = self._engine()
-        w32 = planner_weights_fp32_batch(np.asarray([np.asarray(w, dtype=np.float64).reshape(-1) for w in weights_2d]))
-        init = np.asarray(inits, dtype=np.float32).reshape(-1, 4)
+        if isinstance(weights_2d, np.ndarray) and weights_2d.ndim == 2:
+            W = weights_2d
+        else:
+            W = np.asarray([np.asarray(w, dtype=np.float64).reshape(-1) for w in weights_2d])
+        w32 = planner_weights_fp32_batch(W)
+        init = np.ascontiguousarray(np.asarray(inits, dtype=np.float32).reshape(-1, 4))
         P, N, S = w32.shape[0], init.shape[0], self.num_samples
+        init_dev = self._init_states_dev(eng, init)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             e0, e1 = sharding.episode_range(P, N, S, dist.get_world_size(), dist.get_rank())
-            local = eng.rollout(init, w32, ep_begin=e0, ep_end=e1, to_numpy=False)["returns"]
+            local = eng.rollout(init_dev, w32, ep_begin=e0, ep_end=e1, to_numpy=False)["returns"]
+            if while_running is not None:
+                while_running()
             full = sharding.gather_returns(local, P, N, S)
             ret = full.cpu().numpy()
         else:
-            ret = eng.rollout(init, w32)["returns"]
+            dev = eng.rollout(init_dev, w32, to_numpy=False)["returns"]
+            if while_running is not None:
+                while_running()
+            ret = dev.cpu().numpy()                                # synchronises with the launch stream
         # keep world.reset() side effects in step with the reference (ReplanningCarWorld toggles per reset)
         if hasattr(self.world, "unlucky_car_idx") and (P * N * S) % 2:
             self.world.unlucky_car_idx = 2 if self.world.unlucky_car_idx == 1 else 1
@@ -120,13 +140,16 @@ class MPC_ORD:
     def eval_population(self, weights_2d):
         """[P, D] candidate weights -> [P] costs (-expected designer return), one launch per rank."""
         W = np.asarray(weights_2d, dtype=np.float64).reshape(-1, self.weight_dim)
-        ret = self._returns(self.init_car_states, W)
+        hist = {}
+
+        def normalised_for_history():                           # runs while the GPU works
+            hist["Wn"] = W / np.sqrt(row_dots(W))[:, None]      # np.linalg.norm(row) == sqrt(row.dot(row))
+
+        ret = self._returns(self.init_car_states, W, while_running=normalised_for_history)
         self.last_returns = ret
         P, N, S = ret.shape
         cost = sharding.fitness_from_returns(ret.reshape(-1), P, N, S)
-        n2 = np.array([row.dot(row) for row in W])               # np.linalg.norm(row) == sqrt(row.dot(row))
-        Wn = W / np.sqrt(n2)[:, None]
-        self.history.extend(zip(Wn, -cost))
+        self.history.extend(zip(hist["Wn"], -cost))
         self.iter += P
         if self.should_save_history and self.save_path is not None:
             self.save_history()
@@ -154,12 +177,15 @@ class MPC_ORD:
         self.eval_weights(self.designer_weights)                       # "Iteration 0" baseline
         es = CMAES(list(self.designer_weights), sigma0, popsize=popsize, seed=seed)
         self.generation_seconds = []
+        self.fitness_seconds = []
         while True:
+            t0 = time.perf_counter()                               # a generation: ask, fitness of the population, tell
             X = es.ask()
-            t0 = time.perf_counter()
+            t1 = time.perf_counter()
             f = self.eval_population(X)
-            self.generation_seconds.append(time.perf_counter() - t0)
+            self.fitness_seconds.append(time.perf_counter() - t1)
             es.tell(X, f)
+            self.generation_seconds.append(time.perf_counter() - t0)
             if es.stop(maxiter=maxiter, last_fitness=f) or (maxfevals and es.counteval >= maxfevals):
                 break
         self.should_save_history = False

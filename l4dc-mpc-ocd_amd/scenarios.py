@@ -52,12 +52,40 @@ def planner_weights_fp32_batch(weights_2d) -> np.ndarray:
     W = np.array(weights_2d, dtype=np.float64)
     if W.ndim != 2:
         raise ValueError("weights_2d must be [P, D]")
-    n2 = np.empty(W.shape[0], dtype=np.float64)
     for _ in range(3):
-        for i, row in enumerate(W):
-            n2[i] = row.dot(row)
-        W = W / np.sqrt(n2)[:, None]
+        W = W / np.sqrt(row_dots(W))[:, None]
     return W.astype(np.float32)
+
+
+_ROW_DOTS_BATCHED_OK = {}
+
+
+def _row_dots_loop(W: np.ndarray) -> np.ndarray:
+    n2 = np.empty(W.shape[0], dtype=np.float64)
+    for i, row in enumerate(W):
+        n2[i] = row.dot(row)
+    return n2
+
+
+def _row_dots_batched(W: np.ndarray) -> np.ndarray:
+    return np.matmul(W[:, None, :], W[:, :, None])[:, 0, 0]        # P products (1 x D)(D x 1): numpy's dot kernel per row
+
+
+def row_dots(W: np.ndarray) -> np.ndarray:
+    """row.dot(row) of every row of a float64 [P, D] array, bit for bit what the per-row call returns (the BLAS
+    dot is neither a plain left-to-right sum nor numpy's einsum: 28 % / 43 % of random rows differ).  The batched
+    matmul runs the same dot kernel per row without the Python loop (64 rows: 2.4 us instead of 35 us); that
+    it reproduces the per-row call with THIS numpy / BLAS is checked once per row length on 4 096 random rows,
+    and the loop is used if it ever does not."""
+    W = np.ascontiguousarray(W, dtype=np.float64)
+    D = W.shape[1]
+    ok = _ROW_DOTS_BATCHED_OK.get(D)
+    if ok is None:
+        rng = np.random.RandomState(20240229 + D)
+        T = rng.standard_normal((4096, D)) * np.exp(rng.uniform(-4.0, 4.0, (4096, 1)))
+        ok = bool(np.array_equal(_row_dots_batched(T), _row_dots_loop(T)))
+        _ROW_DOTS_BATCHED_OK[D] = ok
+    return _row_dots_batched(W) if ok else _row_dots_loop(W)
 
 
 def designer_weights_fp32(raw: Sequence[float], raw_dtype=np.float64, pre_normalised: bool = False) -> np.ndarray:

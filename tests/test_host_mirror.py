@@ -234,3 +234,24 @@ def test_history_pickle_format(tmp_path):
     with open(p, "rb") as f:
         g = pickle.load(f)
     assert g[0][1] == -1.5 and list(g[0][0]) == [1, 1, 1]
+
+
+def test_row_dots_is_the_per_row_blas_dot():
+    """The batched norm of the candidate weights must be the per-row call bit for bit (or fall back to it)."""
+    from l4dc_mpc_ocd_amd import scenarios as sc
+    rng = np.random.default_rng(5)
+    for D in (6, 7, 11):
+        W = rng.standard_normal((257, D)) * np.exp(rng.uniform(-6, 6, (257, 1)))
+        ref = np.array([r.dot(r) for r in W])
+        assert np.array_equal(sc.row_dots(W), ref)
+        assert np.array_equal(sc._row_dots_loop(W), ref)
+        assert D in sc._ROW_DOTS_BATCHED_OK
+    # a numpy / BLAS whose batched kernel differed would be caught by the self-check and routed to the loop
+    sc._ROW_DOTS_BATCHED_OK[7] = False
+    try:
+        W = rng.standard_normal((64, 7))
+        assert np.array_equal(sc.row_dots(W), np.array([r.dot(r) for r in W]))
+    finally:
+        del sc._ROW_DOTS_BATCHED_OK[7]
+    for row in rng.standard_normal((50, 7)):
+        assert np.array_equal(sc.planner_weights_fp32_batch(row[None])[0], sc.planner_weights_fp32(row))
