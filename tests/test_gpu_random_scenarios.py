@@ -75,6 +75,11 @@ def test_random_descriptor_bitwise(hip, oracle, case):
     rng = np.random.default_rng(1000 + case)
     scn = random_scenario(rng, H, NO, L)
     d = scn.desc
+    if case % 5 == 1 and L >= 2:                                    # coinciding lane centres: reduce_min ties in every pass
+        d.lane_center[1] = d.lane_center[0]
+    if case % 5 == 2 and NO >= 2:                                   # coinciding scripted cars: lanes with two active collisions
+        for k in range(4):
+            d.other_init[1][k] = d.other_init[0][k]
     eng = Engine(scn, "cuda:0")
     eng.set_option("scan_mode", int(rng.integers(0, 5)))            # any variant the shape allows
     phase = int(rng.integers(0, 3))
