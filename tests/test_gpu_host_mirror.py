@@ -159,6 +159,33 @@ def test_mpc_ord_eval_weights_matches_oracle_fitness(hip, oracle, tmp_path):
     assert world.unlucky_car_idx == 2                           # an even number of resets later
 
 
+def test_validation_drivers_match_oracle(hip, oracle, capsys):
+    """experiments/validate_finite_horizon.py (H = 6 with n_iter = 200 against H = 5) and validate_local_opt.py
+    (3 against 6 control initialisations): the costs the mirrors print are the oracle's."""
+    from l4dc_mpc_ocd_amd.interact_drive.experiments import validate_finite_horizon as vfh, validate_local_opt as vlo
+    got = vfh.main()
+    car, world, _ = finite_horizon_env(horizon=6)
+    inits = vfh.init_states_around(car).astype(np.float32)
+    for H in (6, 5):
+        scn = scenarios.finite_horizon(horizon=H)
+        assert scn.desc.n_iter == (200 if H == 6 else 100)
+        w32 = scenarios.planner_weights_fp32(finite_horizon_env(horizon=H)[0].weights)[None]
+        ret = oracle.rollout(scn.desc, inits, w32)["returns"]
+        assert got[H] == sharding.fitness_from_returns(ret, 1, 3, 1)[0]
+    assert got[6] != got[5]
+    got = vlo.main()
+    from l4dc_mpc_ocd_amd.interact_drive.experiments.local_opt_scenario import local_opt_env
+    car, world, _ = local_opt_env()
+    s0 = np.asarray(car.init_state, dtype=np.float64)
+    inits = np.linspace(s0 - [0., 0.1, 0., 0.], s0 + [0., 0.1, 0., 0.], 3).astype(np.float32)
+    for extra in (False, True):
+        scn = scenarios.local_opt(horizon=5, extra_inits=extra)
+        w32 = scenarios.planner_weights_fp32(local_opt_env(extra_inits=extra)[0].weights)[None]
+        ret = oracle.rollout(scn.desc, inits, w32)["returns"]
+        assert got[extra] == sharding.fitness_from_returns(ret, 1, 3, 1)[0]
+    assert "6 control initialisations" in capsys.readouterr().out
+
+
 def test_evaluate_weights_helper(hip, oracle):
     car, world, inits = finite_horizon_env(horizon=5, env_seeds=[4])
     scn = scenarios.finite_horizon(horizon=5)
