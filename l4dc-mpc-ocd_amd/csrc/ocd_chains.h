@@ -110,6 +110,33 @@ __device__ __forceinline__ void row_fwd_xy(float &x, float &y, float cdb, float 
 #undef OCD_STMT
 }
 
+// H = 10 with the target-speed feature's adjoint in the nine hazard slots (it needs the post-step speed and
+// heading only, which are complete before the position recurrence starts):
+//   vel = vn*sn ; dv = vel - tgt ; sq = dv*dv ; g = (sq <= bound ? w0 : 0)*2 ; g_dv = g*dv ;
+//   qv = g_dv*sn ; qth = (g_dv*vn)*cn                      (reward_one's own sequence, ocd_device.h)
+__device__ __forceinline__ void row_fwd_xy_phi0_h10(float &x, float &y, float cdb, float sdb, float vn, float sn,
+                                                    float cn, float tgt, float bound, float w0, float &qv, float &qth)
+{
+    float t, g;
+#define OCD_XY(FILL) "v_add_f32_dpp %[x], %[x], %[cdb]" OCD_ROW_SHR "v_add_f32_dpp %[y], %[y], %[sdb]" OCD_ROW_SHR FILL
+    asm volatile("s_nop 1\n"
+                 OCD_XY("v_mul_f32 %[t], %[vn], %[sn]\n")
+                 OCD_XY("v_sub_f32 %[t], %[t], %[tgt]\n")
+                 OCD_XY("v_mul_f32 %[g], %[t], %[t]\n")
+                 OCD_XY("v_cmp_le_f32 vcc, %[g], %[bound]\n")
+                 OCD_XY("v_cndmask_b32 %[g], 0, %[w0], vcc\n")
+                 OCD_XY("v_add_f32 %[g], %[g], %[g]\n")
+                 OCD_XY("v_mul_f32 %[g], %[g], %[t]\n")
+                 OCD_XY("v_mul_f32 %[qv], %[g], %[sn]\n")
+                 OCD_XY("v_mul_f32 %[g], %[g], %[vn]\n")
+                 "v_mul_f32 %[qth], %[g], %[cn]\n"
+                 : [x] "+v"(x), [y] "+v"(y), [t] "=&v"(t), [g] "=&v"(g), [qv] "=&v"(qv), [qth] "=&v"(qth)
+                 : [cdb] "v"(cdb), [sdb] "v"(sdb), [vn] "v"(vn), [sn] "v"(sn), [cn] "v"(cn), [tgt] "v"(tgt),
+                   [bound] "v"(bound), [w0] "v"(w0)
+                 : "vcc");
+#undef OCD_XY
+}
+
 // V_SEG: the y chain runs half a round behind the x chain; each chain's add and select cover the other's hazard.
 template <int HT>
 __device__ __forceinline__ void seg_fwd_xy(float &x, float &y, float ex, float ey, float cd, float sd,
@@ -128,6 +155,12 @@ __device__ __forceinline__ void seg_fwd_xy(float &x, float &y, float ex, float e
     OCD_CHAIN_ROUNDS(HT, OCD_STMT);
 #undef OCD_STMT
 }
+
+// (Tried for V_SEG: the position recurrences without boundary selects -- a DPP operand cannot read a lane EXEC
+//  disables, the reader keeps its value, so H-2 rounds with the segments' last lanes disabled plus one closing
+//  step with the first lanes disabled need only one fused DPP add per coordinate and round.  8 instructions
+//  fewer per pass, bit-identical, and 0.9 % SLOWER: the two EXEC writes with their 5 wait states per recurrence
+//  cost more than the selects.  tools/microbench/dpp_exec.hip keeps the probe.)
 
 // ---- adjoint position recurrence (V_SEG):  Lx <- (qx + Lx) of the lane above, 0 in the segment's top lane ----
 template <int HT>

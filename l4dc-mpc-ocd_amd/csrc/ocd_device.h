@@ -341,7 +341,9 @@ __device__ __forceinline__ LaneGradConst<L> lane_grad_const(const float (&w)[OCD
 // pays ~2 issue slots for a branch it does not take and ~5-6 for one it takes (tools/microbench), and at
 // one wavefront per SIMD the launch lasts as long as its slowest wavefront, which has both kinds of lane
 // in nearly every pass: the skips only help where several wavefronts share a SIMD.
-template <int NO, int L, bool GRAD, bool SUB = true>
+// PRE0 (GRAD only): the caller has filled q.qv / q.qth with the target-speed feature's adjoint already (the
+// V_ROW build computes it in the hazard slots of the position recurrence, ocd_chains.h).
+template <int NO, int L, bool GRAD, bool SUB = true, bool PRE0 = false>
 __device__ __forceinline__ float reward_one(const ocd_scenario_desc &d, const float (&w)[OCD_MAX_FEATURES],
                                             float x, float y, float v, float sn, float cn,
                                             const BumpGeom (&bg)[NO > 0 ? NO : 1], const bool (&nc)[NO > 0 ? NO : 1],
@@ -350,6 +352,7 @@ __device__ __forceinline__ float reward_one(const ocd_scenario_desc &d, const fl
                                             const unsigned long long live_mask)
 {
     static_assert(L > 0 && NO > 0, "lane-feature reward only");
+    static_assert(!PRE0 || GRAD, "PRE0 is a gradient-pass option");
     const bool has_col = SUB ? has_col_ : true, has_f = SUB ? has_f_ : true;
     const float tgt = d.target_speed;
     const float bound = 4.0f * (tgt * tgt);
@@ -447,11 +450,13 @@ __device__ __forceinline__ float reward_one(const ocd_scenario_desc &d, const fl
     const v2f Kk = div2_(-M, U);
     const float k1 = Kk.x, k2 = Kk.y;
 #endif
-    const float g_sq = pass0 ? w[0] : 0.0f;
-    const float g_dv = (g_sq * 2.0f) * dv;
-    q.qv = g_dv * sn;
-    const float g_sn = g_dv * v;
-    q.qth = g_sn * cn;
+    if constexpr (!PRE0) {
+        const float g_sq = pass0 ? w[0] : 0.0f;
+        const float g_dv = (g_sq * 2.0f) * dv;
+        q.qv = g_dv * sn;
+        const float g_sn = g_dv * v;
+        q.qth = g_sn * cn;
+    }
 
     // reduce_min over the lanes: the gradient goes to the minimum, split equally among exact ties.  Ties are
     // rare: unless some live lane has one (wave-uniform test), the per-lane factors come precomputed.

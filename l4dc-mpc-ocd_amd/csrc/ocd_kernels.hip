@@ -391,7 +391,15 @@ mpc_kernel(const KernelParams p)
             const float sd = s_pre * dd;
             OCD_STAMP(2);                                  // own step, sincos
             float x = ex, y = ey;
-            if constexpr (asm_chains) {
+            Q4 q;
+            // LAT build of V_ROW at H = 10: the target-speed adjoint goes into the hazard slots of the position
+            // recurrence (ocd_chains.h)
+            constexpr bool phi0_in_chain = LAT && GRAD && asm_chains && V == V_ROW && HT == 10 && lane_feats;
+            if constexpr (phi0_in_chain) {
+                const float tgt = d.target_speed;
+                row_fwd_xy_phi0_h10(x, y, row_below(0.0f, cd), row_below(0.0f, sd), vn, sn, cn, tgt, 4.0f * (tgt * tgt),
+                                    w[0], q.qv, q.qth);
+            } else if constexpr (asm_chains) {
                 if (V == V_ROW) row_fwd_xy<HT>(x, y, row_below(0.0f, cd), row_below(0.0f, sd));
                 else seg_fwd_xy<HT>(x, y, ex, ey, cd, sd, first_mask);
             } else if (V == V_ROW) {
@@ -425,7 +433,6 @@ mpc_kernel(const KernelParams p)
             // ===== reward features at the post-step state =====
             // wave-uniform choice of the evaluation: none of {fence, collisions} active on any live lane /
             // at most one of them per lane (reward_one) / everything (reward_state)
-            Q4 q;
             float r = 0.0f;
             if constexpr (lane_feats) {
                 bool nc[NOA];
@@ -445,7 +452,7 @@ mpc_kernel(const KernelParams p)
                 const unsigned long long any_feat = mf | mc_any;
                 OCD_STAMP(4);                              // choice of the evaluation
                 if constexpr (LAT) {
-                    r = reward_one<NO, L, GRAD, false>(d, w, xn, yn, vn, sn, cn, bg, nc, nf, true, true, q, pkc, lgc, feat_mask);
+                    r = reward_one<NO, L, GRAD, false, phi0_in_chain>(d, w, xn, yn, vn, sn, cn, bg, nc, nf, true, true, q, pkc, lgc, feat_mask);
                     OCD_STAMP(6); OCD_STAMP_COUNT(13);     // one feature per lane
                     if (__builtin_expect(multi != 0ull, 0)) {
                         r = reward_state<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, true, true);
