@@ -7,8 +7,13 @@ One "step" = one generation: launch the episode kernel over this rank's candidat
 fp32 returns (the only collective), copy them to the host and reduce them to per-candidate costs in
 float64 (mpc_ord.py:126-151).  Workload at N GPUs: BASELINE config 3 (local_opt, CMA-ES pop 64 x 32
 inits, H=10, 2 048 episodes -- the largest single-GPU H=10 configuration) PER GPU: weak scaling, the
-population grows with N.  BASELINE config 2 (pop 16 x 8 inits, 128 episodes: the small-batch latency
-case) is timed as a second block of the same JSON line on rank 0.
+population grows with N.  `--scaling strong` keeps the population fixed and splits its candidate blocks
+over the ranks instead (the reference's own parallel axis splits a fixed batch, run_mpc_ord.py:83-90,
+mpc_ord.py:128-137): `--config 4 --gpus 8 --scaling strong` / `--config 5 ...` are BASELINE configs 4 / 5 as
+BASELINE.json states them.  `--emulate-rank R/W` runs, on ONE GPU, exactly the block rank R of a W-way strong
+split would run (config 4: 2 048 episodes at H=15, config 5: 4 096 at H=25, for W=8).
+Extra blocks of the same JSON line on rank 0 (single-GPU runs): BASELINE config 2 (pop 16 x 8 inits, 128
+episodes: the small-batch latency case) and the rank-0-of-8 shares of configs 4 and 5.
 
 `python bench.py --gpus N` starts its N ranks itself (a torch.distributed.run child, spawned before
 anything touches the GPU) unless it already runs under a launcher (WORLD_SIZE set); the world size
@@ -48,6 +53,21 @@ def pmc_record(cfg, n_episodes):
     if not rec or rec.get("episodes_per_launch") != n_episodes:
         return None
     return rec
+
+
+PMC_SOURCE = ("profiles/pmc_counters.json: rocprofv3 --pmc passes of this command on the builder's box "
+              "(tools/profile_round.sh), NOT observed in this run")
+
+
+def parse_emulate(text):
+    """'R/W' -> (R, W)."""
+    try:
+        r, w = (int(v) for v in text.split("/"))
+    except ValueError:
+        raise SystemExit(f"--emulate-rank wants R/W, got {text!r}")
+    if not (w >= 1 and 0 <= r < w):
+        raise SystemExit(f"--emulate-rank {text}: need 0 <= R < W")
+    return r, w
 
 
 def algorithmic_per_episode(desc):
@@ -138,8 +158,14 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config index of the headline workload (2..5)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: the population grows with the ranks (config's pop per GPU); strong: the config's "
+                         "population is split over the ranks (BASELINE configs 4 / 5 on 8 GPUs)")
+    ap.add_argument("--emulate-rank", default="", metavar="R/W",
+                    help="single GPU: run the block that rank R of a W-way strong split would run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the config-2 block and the CMA-ES generation timing")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the config-2 block, the config-4/5 share blocks and the CMA-ES generation timing")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse N>1 on a one-GPU box")
     ap.add_argument("--master-port", type=int, default=0)
@@ -155,6 +181,9 @@ def main():
         raise SystemExit(f"bench.py: world size {world} (WORLD_SIZE) != --gpus {args.gpus}")
     if args.plumbing_check:
         return plumbing_check(args, world, rank)
+    emulate = parse_emulate(args.emulate_rank) if args.emulate_rank else None
+    if emulate and world != 1:
+        raise SystemExit("--emulate-rank runs on one GPU (--gpus 1)")
 
     import torch
     import torch.distributed as dist
@@ -176,35 +205,50 @@ def main():
             dist.init_process_group("gloo")
         assert dist.get_world_size() == args.gpus
 
-    def workload(cfg_index, pop_scale):
+    def workload(cfg_index, P):
         cfg = scenarios.BASELINE_CONFIGS[cfg_index]
         scn = scenarios.SCENARIOS[cfg["scenario"]](horizon=cfg["horizon"])
         N, S = cfg["n_inits"], scn.desc.n_samples
-        P = cfg["pop"] * pop_scale
         inits = scn.init_dist.sample(N, seed=1000 + cfg_index)
         cands = scn.candidate_weights(P, seed=2000 + cfg_index)
         w32 = np.stack([scenarios.planner_weights_fp32(c) for c in cands])
         return cfg, scn, inits, w32, P, N, S
 
-    def timed_generations(cfg_index, pop_scale, ranks, rnk, steps, warmup):
-        """(seconds for `steps` generations, kernel ms, fitness, context) of one workload."""
-        cfg, scn, inits, w32, P, N, S = workload(cfg_index, pop_scale)
+    def timed_generations(cfg_index, P, ranks, rnk, steps, warmup, collective=True):
+        """(seconds for `steps` generations, kernel ms, fitness, context) of one workload: the population P split
+        into `ranks` candidate blocks, this process running block `rnk` (collective=False: the other blocks are
+        nobody's -- rank emulation on one GPU -- and the fitness covers this block's candidates only)."""
+        cfg, scn, inits, w32, P, N, S = workload(cfg_index, P)
         eng = Engine(scn, device)
         init_dev = torch.as_tensor(inits, dtype=torch.float32).to(device)
         w_dev = torch.as_tensor(w32).to(device)                 # inputs resident in HBM before timing
         e0, e1 = sharding.episode_range(P, N, S, ranks, rnk)
         ret_dev = torch.empty(e1 - e0, dtype=torch.float32, device=device)
-        sharded = ranks > 1
+        sharded = ranks > 1 and collective
+        lo, hi = sharding.candidate_block(P, ranks, rnk)
+        host = torch.empty(P * N * S, dtype=torch.float32).pin_memory()     # one pinned buffer, one event per step
+        host_np = host.numpy()
+        done = torch.cuda.Event()
+
+        out_ptr = ret_dev.data_ptr() if sharded else host.data_ptr()   # one process: the kernel writes its returns
+        n_out = e1 - e0                                                #   straight into the pinned host buffer
 
         def generation():
             eng._call(eng.lib.ocd_rollout_episodes, eng._h, init_dev.data_ptr(), w_dev.data_ptr(), P, N, e0, e1,
-                      ret_dev.data_ptr(), None, None, eng._stream())
-            if sharded:
-                local = ret_dev if args.backend == "nccl" else ret_dev.cpu()
-                full = sharding.gather_returns(local, P, N, S)
-            else:
-                full = ret_dev
-            return sharding.fitness_from_returns(full.cpu().numpy(), P, N, S)
+                      out_ptr, None, None, eng._stream())
+            if not sharded:
+                done.record()
+                done.synchronize()
+                return sharding.fitness_from_returns(host_np[:n_out], hi - lo, N, S)
+            src = sharding.gather_returns(ret_dev, P, N, S)
+            if src.is_cuda:
+                host.copy_(src, non_blocking=True)
+                done.record()
+                done.synchronize()
+                arr = host_np
+            else:                                                   # gloo rehearsal: gathered on the host already
+                arr = src.numpy()
+            return sharding.fitness_from_returns(arr, P, N, S)
 
         for _ in range(warmup):
             generation()
@@ -226,53 +270,88 @@ def main():
         kern_ms = eng.time_rollout(init_dev, w_dev, e0, e1, ret_dev, reps=max(3, min(steps, 20)))
         return dt, kern_ms, fit, (cfg, scn, inits, w32, P, N, S, e1 - e0)
 
-    def block(cfg_index, dt, kern_ms, ctx, steps):
+    def share_block(cfg_index, r, w, steps, warmup):
+        """Rank r's block of a w-way strong split of BASELINE config cfg_index, on this GPU alone."""
+        P = scenarios.BASELINE_CONFIGS[cfg_index]["pop"]
+        dt_, k_, fit_, ctx_ = timed_generations(cfg_index, P, w, r, steps, warmup, collective=False)
+        b = block(cfg_index, dt_, k_, ctx_, steps, per_gpu_only=True)
+        b["emulated_rank"] = f"{r}/{w}"
+        b["generation_cost_checksum"] = float(np.sum(fit_))
+        return b
+
+    def block(cfg_index, dt, kern_ms, ctx, steps, per_gpu_only=False):
         cfg, scn, inits, w32, P, N, S, n_local = ctx
+        n_done = n_local if per_gpu_only else P * N * S           # episodes this timing covers per step
         d = scn.desc
         nbytes, flops = algorithmic_per_episode(d)
         ach_gbs = n_local * nbytes / (kern_ms * 1e-3) / 1e9
         ach_tf = n_local * flops / (kern_ms * 1e-3) / 1e12
         pmc = pmc_record(cfg_index, n_local)
+        n_split = max(1, round(P * N * S / max(n_local, 1)))
         traffic = (pmc["fetch_kib"] + pmc["write_kib"]) * 1024.0 if pmc else None
+        profiled = None
         valu = {"achieved": ach_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / VALU_PEAK_TFLOPS,
                 "algorithmic_flops_per_episode": flops,
                 "note": "at one wavefront per SIMD (2 048 episodes at H=10) a lone wavefront issues one instruction per "
                         "~4.4 cycles: one instruction per algorithmic flop would give ~21 % of the vector peak at this batch size (DESIGN.md section 4)"}
-        if pmc and pmc.get("sq_wave_cycles"):
-            # quad-cycles in which a wavefront issued a VALU instruction / quad-cycles wavefronts were resident
-            valu["issue_utilisation"] = pmc["sq_active_inst_valu"] / pmc["sq_wave_cycles"]
-            valu["wait_fraction"] = pmc["sq_wait_any"] / pmc["sq_wave_cycles"]
-            valu["valu_instructions_per_launch"] = pmc["sq_insts_valu"]
-        return {
-            "workload": f"BASELINE config {cfg_index}: {cfg['scenario']}, CMA-ES pop {cfg['pop']} per GPU x {N} inits x "
+        if pmc:
+            # counters REPLAYED from the committed profile of this same command, not measured in this run
+            profiled = {"source": PMC_SOURCE, "hbm_bytes_per_launch": traffic}
+            if pmc.get("sq_wave_cycles"):
+                # quad-cycles in which a wavefront issued a VALU instruction / quad-cycles wavefronts were resident
+                profiled["valu_issue_utilisation"] = pmc["sq_active_inst_valu"] / pmc["sq_wave_cycles"]
+                profiled["wait_fraction"] = pmc["sq_wait_any"] / pmc["sq_wave_cycles"]
+                profiled["valu_instructions_per_launch"] = pmc["sq_insts_valu"]
+        pop_text = (f"pop {P} split over {n_split} ranks" if n_split > 1 else f"pop {P}")
+        out = {
+            "workload": f"BASELINE config {cfg_index}: {cfg['scenario']}, CMA-ES {pop_text} x {N} inits x "
                         f"{S} samples, planning horizon H={d.horizon}, n_iter={d.n_iter}, K={d.n_ctrl_inits} control "
                         f"inits, episode length T={d.episode_len}",
             "episodes_per_generation": P * N * S, "episodes_per_gpu": n_local,
-            "value": P * N * S * steps / dt, "unit": "episodes/s", "ms_per_step": dt / steps * 1e3,
+            "value": n_done * steps / dt, "unit": "episodes/s", "ms_per_step": dt / steps * 1e3,
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "ocd::mpc_kernel", "kernel_ms": kern_ms, "algorithmic_bytes_per_episode": nbytes,
+                         "traffic_source": PMC_SOURCE if pmc else None,
+                         "kernel": "ocd::mpc_kernel / ocd::mpc_chunk_kernel", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_episode": nbytes,
                          "note": "path is fp32-VALU issue bound, not HBM bound (SURVEY.md 8d); see valu"},
             "valu": valu,
         }
+        if profiled:
+            out["profiled"] = profiled
+        return out
 
-    # ---- headline: weak scaling of the chosen config over the ranks ----
-    dt, kern_ms, fit, ctx = timed_generations(args.config, world, world, rank, args.steps, args.warmup)
+    # ---- headline: the chosen config over the ranks (weak: pop per GPU; strong: pop split) ----
+    pop = scenarios.BASELINE_CONFIGS[args.config]["pop"]
+    if emulate:
+        dt, kern_ms, fit, ctx = timed_generations(args.config, pop, emulate[1], emulate[0], args.steps, args.warmup,
+                                                  collective=False)
+    else:
+        P_total = pop * world if args.scaling == "weak" else pop
+        if P_total < world:
+            raise SystemExit(f"bench.py: population {P_total} < {world} ranks")
+        dt, kern_ms, fit, ctx = timed_generations(args.config, P_total, world, rank, args.steps, args.warmup)
 
     # ---- extras: config 2 (small-batch latency) on rank 0, CMA-ES generation wall-clock on all ranks ----
     extra2 = None
+    shares = {}
     cma = None
     if not args.no_extras:
         if rank == 0 and args.config != 2:
-            dt2, k2, _, ctx2 = timed_generations(2, 1, 1, 0, args.steps, args.warmup)
+            dt2, k2, _, ctx2 = timed_generations(2, scenarios.BASELINE_CONFIGS[2]["pop"], 1, 0, args.steps, args.warmup)
             extra2 = block(2, dt2, k2, ctx2, args.steps)
+        if rank == 0 and world == 1 and not emulate:
+            # what ONE of 8 GPUs runs of BASELINE configs 4 / 5 (strong split): the shapes the 8-GPU lines are made of
+            n_sh = max(3, min(args.steps, 20))
+            shares = {f"config{c}_share8": share_block(c, 0, 8, n_sh, 2) for c in (4, 5)}
         # ask -> host normalisation -> H2D -> launch -> (gather) -> D2H -> float64 reduction -> tell, through
         # MPC_ORD.optimize_cmaes (mpc_ord.py:33-45); every rank runs the same deterministic strategy
         from l4dc_mpc_ocd_amd.interact_drive.experiments import run_mpc_ord as rmo
         cfg = scenarios.BASELINE_CONFIGS[args.config]
         m = rmo.make_mpc_ord(cfg["scenario"], horizon=cfg["horizon"], n_inits=cfg["n_inits"], seed=1)
         gens = 12
-        m.optimize_cmaes(seed=1, sigma0=0.05, popsize=cfg["pop"] * world, maxiter=gens)
+        cma_pop = cfg["pop"] * world if args.scaling == "weak" else cfg["pop"]
+        m.optimize_cmaes(seed=1, sigma0=0.05, popsize=cma_pop, maxiter=gens)
         gs = np.array(m.generation_seconds[1:]) * 1e3           # the first generation pays one-off setup
         fs = np.array(m.fitness_seconds[1:]) * 1e3              # eval_population alone (no ask / tell)
         if world > 1:
@@ -282,14 +361,16 @@ def main():
         else:
             med = float(np.median(gs))
         cma = {"cma_generation_ms": med, "fitness_ms": float(np.median(fs)), "generations_timed": int(len(gs)),
-               "popsize": cfg["pop"] * world,
-               "n_inits": cfg["n_inits"], "path": "MPC_ORD.optimize_cmaes: ask, normalise, H2D, launch, gather, D2H, "
-                                                   "float64 reduction, tell (own CMA-ES; pycma is not installed)"}
+               "popsize": cma_pop,
+               "host_split_ms": m.host_split_ms() if hasattr(m, "host_split_ms") else None,
+               "n_inits": cfg["n_inits"], "path": "MPC_ORD.optimize_cmaes: ask, host normalisation into pinned memory the kernel reads, launch, "
+                                                   "(gather,) returns written to / copied into pinned host memory, float64 "
+                                                   "reduction, tell (own CMA-ES; pycma is not installed)"}
 
     if rank == 0:
         cfg, scn, inits, w32, P, N, S, n_local = ctx
         d = scn.desc
-        hb = block(args.config, dt, kern_ms, ctx, args.steps)
+        hb = block(args.config, dt, kern_ms, ctx, args.steps, per_gpu_only=bool(emulate))
         out = {
             "metric": f"MPC episode rollouts/sec at H={d.horizon} (one CMA-ES generation's fitness evaluation); "
                       f"CMA-ES generation wall-clock",
@@ -300,13 +381,15 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": hb["ms_per_step"],
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if (emulate or args.scaling == "strong") else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": hb["workload"], "episodes_per_generation": hb["episodes_per_generation"],
                        "episodes_per_gpu": hb["episodes_per_gpu"],
-                       "sharding": f"candidate blocks over {world} rank(s); one all_gather of fp32 returns per generation"},
+                       "sharding": (f"rank {emulate[0]} of a {emulate[1]}-way strong split, emulated on one GPU (no collective)"
+                                    if emulate else
+                                    f"candidate blocks over {world} rank(s); one all_gather of fp32 returns per generation")},
             "roofline": hb["roofline"],
             "valu": hb["valu"],
             "generation_cost_checksum": float(np.sum(fit)),
@@ -314,9 +397,12 @@ def main():
         if cma:
             out["cma_generation_ms"] = cma["cma_generation_ms"]
             out["cma"] = cma
+        if hb.get("profiled"):
+            out["profiled"] = hb["profiled"]
         if extra2:
             out["config2"] = extra2
-        if world == 1 and not args.no_cpu_baseline:
+        out.update(shares)
+        if world == 1 and not args.no_cpu_baseline and not emulate:
             out["cpu_baseline"] = cpu_baseline(scn, inits, w32)
         print(json.dumps(out))
     if world > 1:

@@ -36,7 +36,8 @@ class CMAES:
         self.gen = 0
         self.counteval = 0
         self._z = None
-        self.best_x, self.best_f = None, np.inf
+        self._best_x, self._best_f = None, np.inf
+        self._told = None
 
     def ask(self):
         """lambda candidate vectors [lam, n]."""
@@ -47,26 +48,53 @@ class CMAES:
     def tell(self, X, fitness):
         fitness = np.asarray(fitness, dtype=np.float64)
         order = np.argsort(fitness, kind="stable")
-        if fitness[order[0]] < self.best_f:
-            self.best_f, self.best_x = float(fitness[order[0]]), np.array(X[order[0]])
+        self._told = (X, fitness, order[0])                        # best-so-far bookkeeping: finish_tell()
         self.counteval += len(fitness)
         n = self.n
+        if self.invsqrtC is None:                                   # finish_tell() was not called in between
+            self.invsqrtC = (self.B / self.Dg) @ self.B.T
         ysel = self._y[order[: self.mu]]
         yw = self.weights @ ysel
         self.mean = self.mean + self.sigma * yw
         self.ps = (1 - self.cs) * self.ps + np.sqrt(self.cs * (2 - self.cs) * self.mueff) * (self.invsqrtC @ yw)
-        hsig = (np.linalg.norm(self.ps) / np.sqrt(1 - (1 - self.cs) ** (2 * self.counteval / self.lam)) / self.chiN
+        ps_norm = np.sqrt(self.ps.dot(self.ps))
+        hsig = (ps_norm / np.sqrt(1 - (1 - self.cs) ** (2 * self.counteval / self.lam)) / self.chiN
                 < 1.4 + 2 / (n + 1))
         self.pc = (1 - self.cc) * self.pc + hsig * np.sqrt(self.cc * (2 - self.cc) * self.mueff) * yw
         rank_mu = (ysel.T * self.weights) @ ysel
-        self.C = ((1 - self.c1 - self.cmu) * self.C
-                  + self.c1 * (np.outer(self.pc, self.pc) + (1 - hsig) * self.cc * (2 - self.cc) * self.C)
-                  + self.cmu * rank_mu)
-        self.sigma *= np.exp((self.cs / self.damps) * (np.linalg.norm(self.ps) / self.chiN - 1))
-        ev, self.B = np.linalg.eigh(self.C)                         # reads the lower triangle only
+        C = ((1 - self.c1 - self.cmu) * self.C
+             + self.c1 * (np.outer(self.pc, self.pc) + (1 - hsig) * self.cc * (2 - self.cc) * self.C)
+             + self.cmu * rank_mu)
+        # rank_mu is symmetric only up to rounding: keep C bit-symmetric, so that what eigh reads (the lower
+        # triangle) and what any other reader of C sees are the same matrix
+        self.C = (C + C.T) * 0.5
+        self.sigma *= np.exp((self.cs / self.damps) * (ps_norm / self.chiN - 1))
+        ev, self.B = np.linalg.eigh(self.C)
         self.Dg = np.sqrt(np.maximum(ev, 1e-20))
-        self.invsqrtC = (self.B / self.Dg) @ self.B.T
+        self.invsqrtC = None                                       # needed by the NEXT tell only: finish_tell()
         self.gen += 1
+
+    def finish_tell(self):
+        """The part of tell() the next ask() does not need (C^-1/2 for the next path update, best-so-far): callers
+        with something to wait for -- a running GPU generation -- call it meanwhile; tell() / best_x catch up
+        otherwise."""
+        if self.invsqrtC is None:
+            self.invsqrtC = (self.B / self.Dg) @ self.B.T
+        if self._told is not None:
+            X, fitness, i = self._told
+            if fitness[i] < self._best_f:
+                self._best_f, self._best_x = float(fitness[i]), np.array(X[i])
+            self._told = None
+
+    @property
+    def best_x(self):
+        self.finish_tell()
+        return self._best_x
+
+    @property
+    def best_f(self):
+        self.finish_tell()
+        return self._best_f
 
     def stop(self, tolfun=1e-11, tolx=1e-11, maxiter=None, last_fitness=None):
         if maxiter is not None and self.gen >= maxiter:

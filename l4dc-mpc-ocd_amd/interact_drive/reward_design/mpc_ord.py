@@ -14,7 +14,7 @@ from .cmaes import CMAES
 from .. import experiments  # noqa: F401
 from ..experiments._sampling import make_get_init_state
 from .._describe import describe, engine_for
-from ... import sharding
+from ... import abi, sharding
 from ...scenarios import planner_weights_fp32, planner_weights_fp32_batch, row_dots
 
 
@@ -60,6 +60,10 @@ class MPC_ORD:
         self.num_samples = num_samples
         self.verbose = False
         self.last_returns = None
+        self.host_split = {}
+        self._pending_history = None
+        self._defer_history = False
+        self._overlap_hooks = []
 
     # ------------------------------------------------------------------ GPU plumbing
     def _engine(self):
@@ -79,12 +83,55 @@ class MPC_ORD:
             self._init_dev_key = key
         return self._init_dev
 
+    def _staging(self, eng, P, N, S, D, n_local):
+        """Buffers of one (device, shape), allocated once.  The candidate weights and the returns live in PINNED
+        host memory that the GPU addresses directly (HIP maps pinned allocations into the device's address space):
+        the kernel reads its 7 weights per trajectory and writes its one return per episode over the link itself,
+        so a single-process generation is one launch and one event wait -- no copy calls.  Sharded runs keep a
+        device buffer for the returns, which the RCCL all-gather needs."""
+        import torch
+        key = (str(eng.device), P, N, S, D, n_local)
+        st = getattr(self, "_stage", None)
+        if st is None or st["key"] != key:
+            st = dict(key=key,
+                      w_host=torch.empty((P, D), dtype=torch.float32).pin_memory(),
+                      ret_dev=torch.empty((n_local,), dtype=torch.float32, device=eng.device),
+                      ret_host=torch.empty((P * N * S,), dtype=torch.float32).pin_memory(),
+                      done=torch.cuda.Event())
+            st["w_np"] = st["w_host"].numpy()
+            st["ret_np"] = st["ret_host"].numpy()
+            st["w_ptr"] = st["w_host"].data_ptr()
+            st["ret_dev_ptr"] = st["ret_dev"].data_ptr()
+            st["ret_host_ptr"] = st["ret_host"].data_ptr()
+            self._stage = st
+        return st
+
+    def _flush_history(self):
+        """Append the last generation's (normalised weights, reward) entries (mpc_ord.py:146).  Inside
+        optimize_cmaes this runs while the NEXT generation's kernel does; everywhere else immediately."""
+        if self._pending_history is not None:
+            Wn, cost = self._pending_history
+            self.history.extend(zip(Wn, -cost))
+            self._pending_history = None
+
+    def _tick(self, name, t0):
+        """Accumulate host-side wall time of one segment of a generation (bench.py reports the medians)."""
+        t1 = time.perf_counter()
+        self.host_split.setdefault(name, []).append(t1 - t0)
+        return t1
+
+    def host_split_ms(self):
+        """Median milliseconds per generation of each host-side segment since optimize_cmaes started
+        (the first generation, which pays allocations, is dropped)."""
+        return {k: float(np.median(v[1:] if len(v) > 1 else v) * 1e3) for k, v in self.host_split.items()}
+
     def _returns(self, inits, weights_2d, while_running=None):
         """fp32 sample rewards [P, N, S] of every (candidate, init, sample) episode; sharded when distributed.
         `while_running()` (host bookkeeping that does not need the returns) runs between launch and readback."""
         import torch
         import torch.distributed as dist
-        eng = self._engine()
+        t = time.perf_counter()
+        eng = getattr(self, "_eng_fixed", None) or self._engine()
         if isinstance(weights_2d, np.ndarray) and weights_2d.ndim == 2:
             W = weights_2d
         else:
@@ -93,18 +140,29 @@ class MPC_ORD:
         init = np.ascontiguousarray(np.asarray(inits, dtype=np.float32).reshape(-1, 4))
         P, N, S = w32.shape[0], init.shape[0], self.num_samples
         init_dev = self._init_states_dev(eng, init)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            e0, e1 = sharding.episode_range(P, N, S, dist.get_world_size(), dist.get_rank())
-            local = eng.rollout(init_dev, w32, ep_begin=e0, ep_end=e1, to_numpy=False)["returns"]
-            if while_running is not None:
-                while_running()
-            full = sharding.gather_returns(local, P, N, S)
-            ret = full.cpu().numpy()
-        else:
-            dev = eng.rollout(init_dev, w32, to_numpy=False)["returns"]
-            if while_running is not None:
-                while_running()
-            ret = dev.cpu().numpy()                                # synchronises with the launch stream
+        sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        e0, e1 = sharding.episode_range(P, N, S, dist.get_world_size(), dist.get_rank()) if sharded else (0, P * N * S)
+        st = self._staging(eng, P, N, S, w32.shape[1], e1 - e0)
+        t = self._tick("normalise", t)
+        dev_index = eng.device.index
+        if torch.cuda.current_device() != dev_index:
+            torch.cuda.set_device(dev_index)
+        st["w_np"][...] = w32                                      # the kernel reads the pinned rows directly
+        stream = torch.cuda.current_stream()
+        abi.check(eng.lib, eng.lib.ocd_rollout_episodes(
+            eng._h, init_dev.data_ptr(), st["w_ptr"], P, N, e0, e1,
+            st["ret_dev_ptr"] if sharded else st["ret_host_ptr"], None, None, stream.cuda_stream))
+        t = self._tick("launch", t)
+        if while_running is not None:
+            while_running()
+        t = self._tick("overlapped_bookkeeping", t)
+        if sharded:
+            full = sharding.gather_returns(st["ret_dev"], P, N, S)
+            st["ret_host"].copy_(full, non_blocking=full.is_cuda)   # (gloo rehearsal: gathered on the host already)
+        st["done"].record(stream)
+        st["done"].synchronize()                                   # the launch (and the gather and its copy) are done
+        ret = st["ret_np"].copy()
+        t = self._tick("kernel_gather_readback", t)
         # keep world.reset() side effects in step with the reference (ReplanningCarWorld toggles per reset)
         if hasattr(self.world, "unlucky_car_idx") and (P * N * S) % 2:
             self.world.unlucky_car_idx = 2 if self.world.unlucky_car_idx == 1 else 1
@@ -142,15 +200,22 @@ class MPC_ORD:
         W = np.asarray(weights_2d, dtype=np.float64).reshape(-1, self.weight_dim)
         hist = {}
 
-        def normalised_for_history():                           # runs while the GPU works
+        def bookkeeping():                                      # runs while the GPU works
+            self._flush_history()                               # the previous generation's entries (deferred)
+            for hook in self._overlap_hooks:
+                hook()
             hist["Wn"] = W / np.sqrt(row_dots(W))[:, None]      # np.linalg.norm(row) == sqrt(row.dot(row))
 
-        ret = self._returns(self.init_car_states, W, while_running=normalised_for_history)
+        ret = self._returns(self.init_car_states, W, while_running=bookkeeping)
+        t = time.perf_counter()
         self.last_returns = ret
         P, N, S = ret.shape
         cost = sharding.fitness_from_returns(ret.reshape(-1), P, N, S)
-        self.history.extend(zip(hist["Wn"], -cost))
+        self._pending_history = (hist["Wn"], cost)
+        if not self._defer_history:
+            self._flush_history()
         self.iter += P
+        self._tick("reduce", t)
         if self.should_save_history and self.save_path is not None:
             self.save_history()
         return cost
@@ -178,16 +243,26 @@ class MPC_ORD:
         es = CMAES(list(self.designer_weights), sigma0, popsize=popsize, seed=seed)
         self.generation_seconds = []
         self.fitness_seconds = []
+        self.host_split = {}
+        self._eng_fixed = self._engine()                           # world and car do not change inside the loop
+        self._defer_history = self.save_path is None               # (a saved history must be complete at every dump)
+        self._overlap_hooks = [es.finish_tell]
         while True:
             t0 = time.perf_counter()                               # a generation: ask, fitness of the population, tell
             X = es.ask()
-            t1 = time.perf_counter()
+            t1 = self._tick("ask", t0)
             f = self.eval_population(X)
-            self.fitness_seconds.append(time.perf_counter() - t1)
+            t2 = time.perf_counter()
+            self.fitness_seconds.append(t2 - t1)
             es.tell(X, f)
+            self._tick("tell", t2)
             self.generation_seconds.append(time.perf_counter() - t0)
             if es.stop(maxiter=maxiter, last_fitness=f) or (maxfevals and es.counteval >= maxfevals):
                 break
+        self._eng_fixed = None
+        self._defer_history = False
+        self._overlap_hooks = []
+        self._flush_history()
         self.should_save_history = False
         self.done = True
         self.es = es
@@ -209,6 +284,7 @@ class MPC_ORD:
 
     def save_history(self):
         assert self.save_path is not None
+        self._flush_history()
         with open(self.save_path, 'wb') as file:
             pickle.dump(self.history, file)
 

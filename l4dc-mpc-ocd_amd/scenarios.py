@@ -49,11 +49,24 @@ def planner_weights_fp32_batch(weights_2d) -> np.ndarray:
     """[P, D] candidate weights -> [P, D] fp32, row by row exactly `planner_weights_fp32` (np.linalg.norm of a
     1-D float64 vector is sqrt(x.dot(x)); the same BLAS dot is called per row here), without its per-row
     Python overhead: the host side of a CMA-ES generation is otherwise dominated by this."""
-    W = np.array(weights_2d, dtype=np.float64)
+    W = np.array(weights_2d, dtype=np.float64)                     # a contiguous private copy
     if W.ndim != 2:
         raise ValueError("weights_2d must be [P, D]")
-    for _ in range(3):
-        W = W / np.sqrt(row_dots(W))[:, None]
+    if _ROW_DOTS_BATCHED_OK.get(W.shape[1]) is None:
+        row_dots(W)                                                 # runs the one-off self-check for this row length
+    if _ROW_DOTS_BATCHED_OK[W.shape[1]]:
+        # the same three operations per pass (dot, sqrt, divide) in place: a CMA-ES generation pays this on its
+        # critical path, and at 64 x 7 the cost is numpy call overhead, not arithmetic
+        row, col = W[:, None, :], W[:, :, None]
+        n2 = np.empty((W.shape[0], 1, 1), dtype=np.float64)
+        nrm = n2.reshape(-1, 1)
+        for _ in range(3):
+            np.matmul(row, col, out=n2)
+            np.sqrt(n2, out=n2)
+            np.divide(W, nrm, out=W)
+    else:
+        for _ in range(3):
+            W = W / np.sqrt(_row_dots_loop(W))[:, None]
     return W.astype(np.float32)
 
 

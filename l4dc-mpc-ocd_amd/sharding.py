@@ -38,6 +38,8 @@ def gather_returns(local: torch.Tensor, P: int, N: int, S: int, group: Optional[
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local
     ws = dist.get_world_size(group)
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        local = local.cpu()                  # rehearsal backend: gloo gathers host tensors (RCCL takes device memory)
     sizes = [(candidate_block(P, ws, r)[1] - candidate_block(P, ws, r)[0]) * N * S for r in range(ws)]
     m = max(sizes)
     if local.numel() != sizes[dist.get_rank(group)]:

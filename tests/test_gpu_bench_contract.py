@@ -19,7 +19,8 @@ def test_bench_json_line():
     assert len(lines) == 1
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "cma_generation_ms", "config2"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "cma_generation_ms", "config2",
+              "config4_share8", "config5_share8"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["dtype"] == "f32" and d["data"] == "synthetic"
     assert d["vs_baseline"] is None and d["higher_is_better"] is True and d["scaling"] == "weak"
@@ -39,3 +40,16 @@ def test_bench_json_line():
     assert d["cma_generation_ms"] > rf["kernel_ms"] * 0.9
     assert d["config2"]["episodes_per_generation"] == 128 and d["config2"]["value"] > 0
     assert 0 < d["valu"]["frac"] < 1
+    # counters replayed from the committed profile say so, and live apart from the measured objects
+    assert "issue_utilisation" not in d["valu"]
+    if rf["traffic"] is not None:
+        assert "NOT observed in this run" in rf["traffic_source"] and d["profiled"]["source"] == rf["traffic_source"]
+    # the per-GPU shares of BASELINE configs 4 / 5 over 8 GPUs, run on this one GPU
+    s4, s5 = d["config4_share8"], d["config5_share8"]
+    assert s4["episodes_per_gpu"] == 2048 and s4["episodes_per_generation"] == 16384 and s4["emulated_rank"] == "0/8"
+    assert s5["episodes_per_gpu"] == 4096 and s5["episodes_per_generation"] == 32768
+    for sb in (s4, s5):
+        assert abs(sb["value"] - sb["episodes_per_gpu"] / (sb["ms_per_step"] * 1e-3)) / sb["value"] < 1e-6
+        assert sb["roofline"]["kernel_ms"] <= sb["ms_per_step"] * 1.02
+    sp = d["cma"]["host_split_ms"]
+    assert set(sp) >= {"ask", "normalise", "launch", "kernel_gather_readback", "reduce", "tell"}

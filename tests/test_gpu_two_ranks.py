@@ -1,0 +1,56 @@
+"""HIP kernels + sharding + gather composed: bench.py as two ranks on the one GPU of the box (gloo rendezvous,
+both ranks launching on the same card) must reproduce the one-rank generation bit for bit under strong
+scaling, and the rank-emulation mode must run exactly one rank's block.
+
+The ranks are child processes of a torch.distributed.run child of this test (bench.py's own launcher): two
+GPU processes besides this one, within the box's limit."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def run(args, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, env=env, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+COMMON = ["--steps", "3", "--warmup", "1", "--no-extras", "--no-cpu-baseline"]
+
+
+def test_two_ranks_reproduce_one_rank_under_strong_scaling():
+    one = run(["--gpus", "1", "--scaling", "strong"] + COMMON)
+    port = 29700 + os.getpid() % 200
+    two = run(["--gpus", "2", "--backend", "gloo", "--scaling", "strong", "--master-port", str(port)] + COMMON)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert one["scaling"] == two["scaling"] == "strong"
+    assert one["config"]["episodes_per_generation"] == two["config"]["episodes_per_generation"] == 2048
+    assert two["config"]["episodes_per_gpu"] == 1024
+    # the same 64 candidates, evaluated as two blocks on two processes and gathered: identical costs
+    assert two["generation_cost_checksum"] == one["generation_cost_checksum"]
+
+
+def test_weak_scaling_doubles_the_population():
+    port = 29900 + os.getpid() % 90
+    two = run(["--gpus", "2", "--backend", "gloo", "--master-port", str(port)] + COMMON)
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak"
+    assert two["config"]["episodes_per_generation"] == 4096 and two["config"]["episodes_per_gpu"] == 2048
+
+
+def test_rank_emulation_runs_one_block_of_config_4():
+    d = run(["--config", "4", "--emulate-rank", "3/8"] + COMMON)
+    assert d["n_gpus"] == 1 and d["scaling"] == "strong"
+    assert d["config"]["episodes_per_generation"] == 16384 and d["config"]["episodes_per_gpu"] == 2048
+    assert "rank 3 of a 8-way" in d["config"]["sharding"]
+    # value counts this GPU's episodes only
+    assert abs(d["value"] - 2048 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
