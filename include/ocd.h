@@ -131,7 +131,8 @@ const char *ocd_last_error(void);
 /* Validate a descriptor and build the handle the kernels read their constants
  * from.  Replaces the reference's scenario factories + NaivePlanner.__init__
  * (naive_planner.py:19-30, planner_car.py:49-52).  Any planning horizon in
- * [1, OCD_MAX_HORIZON], 0..OCD_MAX_OTHERS scripted cars and 1..OCD_MAX_LANES lanes run. */
+ * [1, OCD_MAX_HORIZON] runs; the lane-feature reward takes 1..OCD_MAX_OTHERS scripted cars (its collision feature
+ * needs one) and 1..OCD_MAX_LANES lanes, the target-speed test reward 0..OCD_MAX_OTHERS scripted cars. */
 int32_t ocd_scenario_create(const ocd_scenario_desc *desc, ocd_scenario **out);
 void ocd_scenario_destroy(ocd_scenario *scn);
 
@@ -159,8 +160,10 @@ int32_t ocd_scenario_set_option(ocd_scenario *scn, const char *name, int32_t val
  * (naive_planner.py:20,69-70; reward_design/value_interpolation.py:28-61).  When set, the reward of
  * the LAST horizon step is the trilinear interpolation of `values` at the coarse state
  * proj(world_state) instead of car.reward_fn: proj_kind 0 = (x, y, v) of the planning car,
- * 1 = (x, y, v * sin(heading)) (the coarse state of coarse_value_iteration.py:117-124).  NaN outside
- * [grid[0], grid[-1]] in any dimension, like the reference.
+ * 1 = (x, y, v * sin(heading)) (the coarse state of coarse_value_iteration.py:117-124).  Outside
+ * [grid[0], grid[-1]] in any dimension the value is NaN and its gradient ZERO: the reference's traced function
+ * returns the constant float('nan') there (value_interpolation.py:59-60), so the plan's objective is NaN while the
+ * controls keep the finite gradients of the other horizon steps.
  *   grid0/1/2 [n0]/[n1]/[n2]  ascending cell boundaries (ValueFeature.disc_grid), HOST pointers
  *   values    [n0, n1, n2]    one time slice of v_grids (v_grids[t]), HOST pointer
  * The handle copies the table (to every device it launches on).  values == NULL removes it.

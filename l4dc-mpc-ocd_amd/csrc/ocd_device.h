@@ -540,8 +540,8 @@ __device__ __forceinline__ float reward_one(const ocd_scenario_desc &d, const fl
 
 // ---------------------------------------------------------------- terminal value (leaf_evaluation)
 // ValueFeature.interpolate_value (value_interpolation.py:28-61): trilinear interpolation of a value
-// table over the coarse state proj(world_state) = (x, y, v) or (x, y, v*sin(heading)); NaN outside the
-// grid.  Layout and semantics: include/ocd.h, ocd_scenario_set_leaf_value.
+// table over the coarse state proj(world_state) = (x, y, v) or (x, y, v*sin(heading)); outside the grid the
+// value is NaN and its gradient zero.  Layout and semantics: include/ocd.h, ocd_scenario_set_leaf_value.
 struct LeafTable {
     const float *grid;        // [n0 + n1 + n2] cell boundaries, ascending per dimension
     const float *values;      // [n0, n1, n2]
@@ -571,7 +571,9 @@ __device__ __forceinline__ float leaf_value(const LeafTable &lt, float x, float 
 #pragma unroll
     for (int k = 0; k < 3; ++k) inside = inside && (xc[k] >= gr[k][0]) && (xc[k] <= gr[k][lt.n[k] - 1]);
     const float nanv = __int_as_float(0x7fc00000);
-    if (GRAD) { q.qx = nanv; q.qy = nanv; q.qv = nanv; q.qth = nanv; }
+    // outside the grid the traced function returns the CONSTANT float('nan') (value_interpolation.py:59-60): the
+    // value is NaN, its gradient w.r.t. the state is zero -- the other horizon steps keep their finite gradients
+    if (GRAD) { q.qx = 0.0f; q.qy = 0.0f; q.qv = 0.0f; q.qth = 0.0f; }
     if (!inside) return nanv;
     int c[3];
     float a[3], st[3];

@@ -222,6 +222,10 @@ class Engine(DeviceOps):
             raise ValueError(f"controls has {u.shape[0]} rows for {B} world states")
         w = None if weights is None else self._to_dev(weights)
         per = int(w is not None and w.dim() == 2)
+        if w is not None and per and w.shape[0] != B:
+            raise ValueError(f"weights has {w.shape[0]} rows for {B} world states")
+        if w is not None and w.shape[-1] != d.n_features:
+            raise ValueError(f"weights has {w.shape[-1]} features, the scenario {d.n_features}")
         if isinstance(other_plans, str):
             op = self._other_plans
         else:

@@ -25,22 +25,29 @@ class list2(list):  # mutable list that can carry a .seed attribute (mpc_ord.py:
 
 def _pickle_as_reference_list2():
     """History pickles must load in the reference's own scripts (bar_plot.py:105-130, generalization_plot.py:
-    167-177 unpickle `interact_drive.reward_design.mpc_ord.list2`): pickle the class under the reference's
-    module path, and make that path resolve to this mirror in this process unless the real package is there."""
-    import importlib
+    167-177 unpickle `interact_drive.reward_design.mpc_ord.list2`): the class is pickled under the reference's
+    module path.  pickle resolves that dotted name by importing it, parents included, so the leaf name is aliased
+    to this module and -- only where no package of that name is loaded -- the two parents are registered as EMPTY
+    stub packages (`__path__ = []`).  The stubs hold nothing but the chain down to this module: a later
+    `import interact_drive.car` raises ModuleNotFoundError instead of silently loading a second copy of the mirror
+    under another name, and the reference is never imported as a side effect.  If a real `interact_drive` is already
+    loaded, nothing is registered and list2 keeps this module's own path."""
     import sys
+    import types
     ref = "interact_drive.reward_design.mpc_ord"
     here = sys.modules[__name__]
-    pkg_rd = sys.modules[__name__.rsplit(".", 1)[0]]
-    pkg_id = sys.modules[__name__.rsplit(".", 2)[0]]
-    try:
-        mod = importlib.import_module(ref)          # the real reference is installed: its class wins
-        if getattr(mod, "list2", None) is not list2 and mod is not here:
-            return
-    except Exception:
-        sys.modules.setdefault("interact_drive", pkg_id)
-        sys.modules.setdefault("interact_drive.reward_design", pkg_rd)
-        sys.modules.setdefault(ref, here)
+    top, mid = "interact_drive", "interact_drive.reward_design"
+    if top in sys.modules and not getattr(sys.modules[top], "_ocd_pickle_stub", False):
+        return                                                       # the real package (or somebody else's) is loaded
+    for name in (top, mid):
+        if name not in sys.modules:
+            stub = types.ModuleType(name, "stub package: only names the reference path of MPC_ORD history pickles")
+            stub.__path__ = []
+            stub._ocd_pickle_stub = True
+            sys.modules[name] = stub
+    sys.modules[top].reward_design = sys.modules[mid]
+    sys.modules[mid].mpc_ord = here
+    sys.modules[ref] = here
     list2.__module__ = ref
 
 

@@ -289,8 +289,8 @@ static float reward_state(const ocd_scenario_desc *d, const float *w,
 }
 
 /* ---- terminal value: ValueFeature.interpolate_value (value_interpolation.py:28-61) ----
- * Trilinear interpolation of a value table over the coarse state proj(world_state); NaN outside the
- * grid.  The reference never calls it (no scenario sets leaf_evaluation) and holds no vector for it:
+ * Trilinear interpolation of a value table over the coarse state proj(world_state); outside the grid the
+ * value is NaN and its gradient zero (the else-branch returns a constant).  The reference never calls it (no scenario sets leaf_evaluation) and holds no vector for it:
  * PARITY UNPINNED; the op order below (one rounding per TensorFlow op, sum over the 8 corners in
  * itertools.product order, gradient accumulated in that same order) is the contract the HIP kernel shares. */
 static struct {
@@ -316,7 +316,9 @@ static float leaf_value(float x, float y, float v, float sn, float cn, q4 *q)
     int inside = 1;
     for (int k = 0; k < 3; ++k)
         inside = inside && (xc[k] >= g_leaf.grid[k][0]) && (xc[k] <= g_leaf.grid[k][g_leaf.n[k] - 1]);
-    if (q) { q->qx = nanv; q->qy = nanv; q->qv = nanv; q->qth = nanv; }
+    /* outside the grid the traced function returns the CONSTANT float('nan') (value_interpolation.py:59-60): the
+     * value is NaN, its gradient w.r.t. the state is zero -- the other horizon steps keep their finite gradients */
+    if (q) { q->qx = 0.0f; q->qy = 0.0f; q->qv = 0.0f; q->qth = 0.0f; }
     if (!inside) return nanv;
     int c[3];
     float a[3], st[3], p[3][2];

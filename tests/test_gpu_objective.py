@@ -106,10 +106,14 @@ def test_terminal_value_bitwise(oracle, name, H, proj_kind):
             r, g, tr = oracle.mpc_reward(scn.desc, ws[b], w[b], u[b])
             same(out["reward"][b], r, f"R[{b}]"); same(out["grad"][b], g, f"grad[{b}]")
         assert np.isnan(out["reward"][:4]).all() and np.isfinite(out["reward"][4:]).sum() >= 6
+        # outside the grid the value is the CONSTANT nan (value_interpolation.py:59-60): objective NaN, gradient finite
+        # (the other H-1 steps'), nothing flows back from the terminal step, so the last control's gradient is zero
+        assert np.isfinite(out["grad"][:4]).all() and not out["grad"][:4, -1].any()
         ref = oracle.plan_batch(scn.desc, ws, w)
         got = eng.plan_batch(ws, w, want_all=True)
         same(got["all_losses"], ref["all_losses"], "losses"); same(got["all_plans"], ref["all_plans"], "plans")
         assert np.array_equal(got["best_init"], ref["best_init"])
+        assert np.isfinite(got["plans"][:4]).all() and np.isnan(got["best_loss"][:4]).all()   # finite controls, NaN loss
         inits = scn.init_dist.sample(3, seed=9)
         ro = eng.rollout(inits, w[:2], want_traj=True)
         rr = oracle.rollout(scn.desc, inits, w[:2], want_traj=True)

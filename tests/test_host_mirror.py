@@ -246,6 +246,20 @@ def test_history_pickle_loads_in_the_reference(tmp_path):
     assert r.stdout.split() == ["interact_drive.reward_design.mpc_ord", "7", "-2.5", "[0.0,", "1.0,", "2.0]"]
 
 
+def test_pickle_alias_registers_no_mirror_package_under_the_reference_name():
+    """Only the chain of names pickle needs is registered; the mirror's packages are not reachable as
+    `interact_drive.*` (a second copy of the classes would break the isinstance checks in _describe.py)."""
+    import importlib
+    import sys
+    import l4dc_mpc_ocd_amd.interact_drive.reward_design.mpc_ord as m
+    assert sys.modules["interact_drive.reward_design.mpc_ord"] is m
+    assert getattr(sys.modules["interact_drive"], "_ocd_pickle_stub", False)
+    with pytest.raises(ModuleNotFoundError):
+        importlib.import_module("interact_drive.car")
+    with pytest.raises(ModuleNotFoundError):
+        importlib.import_module("interact_drive.planner.naive_planner")
+
+
 def test_history_pickle_format(tmp_path):
     h = __import__("l4dc_mpc_ocd_amd.interact_drive.reward_design.mpc_ord", fromlist=["list2"]).list2()
     h.seed = 5

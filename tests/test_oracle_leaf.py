@@ -62,3 +62,32 @@ def test_terminal_value_matches_numpy_trilinear(oracle):
                     np.testing.assert_allclose(g[0], fd, rtol=2e-2, atol=2e-4)
         finally:
             oracle.set_leaf_value(None, None)
+
+
+def test_out_of_grid_terminal_state_gives_nan_value_and_zero_gradient(oracle):
+    """value_interpolation.py:59-60: outside the grid the traced function returns the constant float('nan'), so the
+    objective is NaN but the terminal step sends NO gradient back: the controls keep the finite gradient of the
+    other horizon steps, and generate_plan returns finite controls."""
+    rng = np.random.default_rng(3)
+    grid = [np.linspace(-0.3, 0.3, 5).astype(np.float32), np.linspace(-1.0, 1.0, 6).astype(np.float32),
+            np.linspace(0.0, 3.0, 4).astype(np.float32)]
+    vals = rng.standard_normal((5, 6, 4)).astype(np.float32)
+    scn = scenarios.finite_horizon(horizon=4)
+    ws = np.zeros((2, 4), dtype=np.float32)
+    ws[0] = [0.02, 5.0, 1.0, np.pi / 2]                              # y = 5 is far outside the y grid [-1, 1]
+    ws[1] = np.array(scn.desc.other_init[0][:])
+    w = scenarios.planner_weights_fp32(scn.raw_designer_weights)
+    u = rng.uniform(-0.5, 0.5, (4, 2)).astype(np.float32)
+    r0, g0, _ = oracle.mpc_reward(scn.desc, ws, w, u)               # no terminal value: the reference gradient
+    oracle.set_leaf_value(grid, vals, 0)
+    try:
+        r, g, _ = oracle.mpc_reward(scn.desc, ws, w, u)
+        assert np.isnan(r) and np.all(np.isfinite(g))
+        # the terminal step contributes nothing: the gradient is that of the first H-1 rewards alone, i.e. the plain
+        # objective's minus what its own last-step reward contributed -- and the last control gets exactly zero
+        assert np.array_equal(g[-1], np.zeros(2, dtype=np.float32))
+        plan = oracle.plan_batch(scn.desc, ws[None], w)
+        assert np.all(np.isfinite(plan["plans"])) and np.all(np.isnan(plan["best_loss"]))
+    finally:
+        oracle.set_leaf_value(None, None)
+    assert np.isfinite(r0) and np.all(np.isfinite(g0))
