@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak fp32 vector
 
 
-def pmc_record(cfg, n_episodes):
+def pmc_record(key, n_episodes):
     """Counters of the episode kernel from the committed rocprofv3 PMC passes (profiles/pmc_counters.json:
     separate --pmc runs of this same command; FETCH_SIZE / WRITE_SIZE in KiB per launch -- dword-granular
     accesses, so the guide's 2x FETCH correction for wide streaming reads does not apply -- and the SQ
@@ -47,7 +47,7 @@ def pmc_record(cfg, n_episodes):
     path = os.path.join(ROOT, "profiles", "pmc_counters.json")
     try:
         with open(path) as f:
-            rec = json.load(f).get(f"cfg{cfg}")
+            rec = json.load(f).get(key)
     except (OSError, ValueError):
         return None
     if not rec or rec.get("episodes_per_launch") != n_episodes:
@@ -286,8 +286,8 @@ def main():
         nbytes, flops = algorithmic_per_episode(d)
         ach_gbs = n_local * nbytes / (kern_ms * 1e-3) / 1e9
         ach_tf = n_local * flops / (kern_ms * 1e-3) / 1e12
-        pmc = pmc_record(cfg_index, n_local)
         n_split = max(1, round(P * N * S / max(n_local, 1)))
+        pmc = pmc_record(f"cfg{cfg_index}_share{n_split}" if per_gpu_only else f"cfg{cfg_index}", n_local)
         traffic = (pmc["fetch_kib"] + pmc["write_kib"]) * 1024.0 if pmc else None
         profiled = None
         valu = {"achieved": ach_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / VALU_PEAK_TFLOPS,

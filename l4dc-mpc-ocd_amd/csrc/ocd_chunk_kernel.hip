@@ -31,7 +31,12 @@
 
 namespace ocd {
 
-template <int HT, int NO, int L, int S>
+// LAT: the launch puts at most one wavefront on a SIMD (the per-GPU shares of BASELINE configs 4 / 5: 1 024
+//   wavefronts), so it lasts as long as its slowest wavefront and nothing hides that wavefront's branches and its
+//   ballot -> SALU -> branch stalls (ocd_kernels.hip, LAT).  This build evaluates reward_one unconditionally and
+//   straight-line for every step of the chunk and repairs the rare step with a multi-feature lane out of line.
+//   The diagnostics knobs no_feature_skips / no_unified_features select the LAT = false build.
+template <int HT, int NO, int L, int S, bool LAT = false>
 __global__ void __launch_bounds__(64) OCD_CHUNK_OCC
 mpc_chunk_kernel(const KernelParams p)
 {
@@ -95,6 +100,7 @@ mpc_chunk_kernel(const KernelParams p)
 
     const int T = p.T;
     const PkConsts pkc = pk_consts();
+    OCD_STAMP_DECL
     float G_ret = 0.0f;
     const BumpGeom bg0 = {0.0f, 1.0f, 0.0f, 1.0f};
     const bool writer = live && kinit == 0 && first;
@@ -195,6 +201,7 @@ mpc_chunk_kernel(const KernelParams p)
 
         auto horizon_pass = [&](auto grad_tag) __attribute__((always_inline)) {
             constexpr bool GRAD = decltype(grad_tag)::value;
+            OCD_STAMP(0);                                  // everything outside the passes
             // ===== forward =====
             float a_c[S], wdt[S];
             bool pass_a[S], pass_w[S];
@@ -222,6 +229,7 @@ mpc_chunk_kernel(const KernelParams p)
                 vs = first ? ev : vb;
                 ths = first ? eth : tb;
             }
+            OCD_STAMP(1);                                  // clip, speed / heading recurrence
             // the lane's own S steps
             float vpre[S], dd[S], vn[S], sn[S], cn[S];
             {
@@ -254,6 +262,7 @@ mpc_chunk_kernel(const KernelParams p)
             float cd[S], sd[S];
 #pragma unroll
             for (int s = 0; s < S; ++s) { cd[s] = c_pre[s] * dd[s]; sd[s] = s_pre[s] * dd[s]; }
+            OCD_STAMP(2);                                  // own steps, sincos
             // position at the start of the chunk
             float xs = ex, ys = ey;
 #pragma unroll
@@ -266,10 +275,56 @@ mpc_chunk_kernel(const KernelParams p)
                 ys = first ? ey : yb;
             }
 
+            OCD_STAMP(3);                                  // position recurrence
             // ===== reward features at the S post-step states =====
             Q4 q[S];
             float rw[S];
-            {
+            if constexpr (lane_feats && LAT) {
+                // the masks of all S steps first (their ballots settle while the evaluations issue); per step one test
+                // chooses between one feature per lane and the rarer multi-feature evaluations; no "none active" path
+                float xn_[S], yn_[S];
+                bool nf_[S], nc_[S][NOA];
+                unsigned long long mf_[S], mc_[S];         // fence + car lanes, two-car lanes
+                {
+                    float x = xs, y = ys;
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        x = x + cd[s];
+                        y = y + sd[s];
+                        xn_[s] = x; yn_[s] = y;
+                        nf_[s] = needs_fence(d, x);
+                        const unsigned long long mf = __builtin_amdgcn_ballot_w64(nf_[s]) & live_mask;
+                        unsigned long long mc_any = 0ull;
+                        mf_[s] = 0ull; mc_[s] = 0ull;
+                        nc_[s][0] = false;
+#pragma unroll
+                        for (int j = 0; j < NO; ++j) {
+                            const float dx = x - bg[s][j].cx, dy = y - bg[s][j].cy;
+                            const bool ncx = __builtin_fabsf(dx) < wx1[s][j], ncy = __builtin_fabsf(dy) < wy1[s][j];
+                            nc_[s][j] = ncx && ncy;
+                            const unsigned long long mj = __builtin_amdgcn_ballot_w64(ncx) & __builtin_amdgcn_ballot_w64(ncy) & live_mask;
+                            mf_[s] |= (mj & mf);
+                            mc_[s] |= (mj & mc_any);
+                            mc_any |= mj;
+                        }
+                    }
+                }
+                OCD_STAMP(4);                              // choice of the evaluation
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    if (__builtin_expect((mf_[s] | mc_[s]) != 0ull, 0)) {
+                        if (mc_[s] != 0ull)
+                            rw[s] = reward_state<NO, L, GRAD>(d, w, xn_[s], yn_[s], vn[s], sn[s], cn[s], bg[s], q[s], nullptr, true, true);
+                        else
+                            rw[s] = reward_fc<NO, L, GRAD>(d, w, xn_[s], yn_[s], vn[s], sn[s], cn[s], bg[s], nc_[s], q[s], pkc);
+                        OCD_STAMP(5); OCD_STAMP_COUNT(12);
+                    } else {
+                        rw[s] = reward_one<NO, L, GRAD, false>(d, w, xn_[s], yn_[s], vn[s], sn[s], cn[s], bg[s], nc_[s], nf_[s], true, true,
+                                                               q[s], pkc, lgc, live_mask);
+                        OCD_STAMP(6); OCD_STAMP_COUNT(13);
+                    }
+                }
+            } else {
                 float x = xs, y = ys;
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
@@ -280,22 +335,32 @@ mpc_chunk_kernel(const KernelParams p)
                         bool nc[NOA];
                         nc[0] = false;
                         const bool nf = needs_fence(d, xn);
-                        unsigned long long mf = __ballot(nf) & live_mask, mc_any = 0ull, multi = 0ull;
+                        unsigned long long mf = __ballot(nf) & live_mask, mc_any = 0ull, multi_f = 0ull, multi_c = 0ull;
 #pragma unroll
                         for (int j = 0; j < NO; ++j) {
                             const float dx = xn - bg[s][j].cx, dy = yn - bg[s][j].cy;
                             nc[j] = (__builtin_fabsf(dx) < wx1[s][j]) && (__builtin_fabsf(dy) < wy1[s][j]);
                             const unsigned long long mj = __ballot(nc[j]) & live_mask;
-                            multi |= (mj & (mf | mc_any));
+                            multi_f |= (mj & mf);          // fence and a car on one lane
+                            multi_c |= (mj & mc_any);      // two cars on one lane
                             mc_any |= mj;
                         }
                         const bool has_f = mf != 0ull, has_col = mc_any != 0ull;
-                        if (p.no_skips || multi != 0ull || (p.no_unify && (has_f || has_col))) {
+                        OCD_STAMP(4);                      // choice of the evaluation
+                        if (p.no_skips || multi_c != 0ull || (p.no_unify && (has_f || has_col))) {
                             rw[s] = reward_state<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], q[s], nullptr, true, true);
+                            OCD_STAMP(5); OCD_STAMP_COUNT(12);
+                        } else if (multi_f != 0ull) {
+                            rw[s] = reward_fc<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], nc, q[s], pkc);
+                            OCD_STAMP(5); OCD_STAMP_COUNT(12);
                         } else if (has_f || has_col) {
                             rw[s] = reward_one<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], nc, nf, has_col, has_f, q[s], pkc, lgc, live_mask);
+                            OCD_STAMP(6); OCD_STAMP_COUNT(13);
+                            if (has_col) OCD_STAMP_COUNT(11);
+                            if (has_f) OCD_STAMP_COUNT(15);
                         } else {
                             rw[s] = reward_state<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], q[s], nullptr, false, false);
+                            OCD_STAMP(7); OCD_STAMP_COUNT(14);
                         }
                     } else {
                         rw[s] = reward_state<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], q[s], nullptr);
@@ -331,6 +396,7 @@ mpc_chunk_kernel(const KernelParams p)
                     LxE = last ? 0.0f : xa;
                     LyE = last ? 0.0f : ya;
                 }
+                OCD_STAMP(8);                              // position adjoint recurrence
                 float tau[S], gv1[S], gA1[S];
                 {
                     float Lx = LxE, Ly = LyE;
@@ -365,6 +431,7 @@ mpc_chunk_kernel(const KernelParams p)
                     LvE = last ? 0.0f : va;
                     LthE = last ? 0.0f : ta;
                 }
+                OCD_STAMP(9);                              // Jacobian products, speed / heading adjoint recurrence
                 {
                     float Lv = LvE, Lth = LthE;
 #pragma unroll
@@ -383,6 +450,7 @@ mpc_chunk_kernel(const KernelParams p)
                         uw[s] = uw[s] + lr * grad_w;
                     }
                 }
+                OCD_STAMP(10);                             // own steps' adjoint, control update
             }
         };
 
@@ -459,6 +527,11 @@ mpc_chunk_kernel(const KernelParams p)
         }
     }
     if (p.mode == OCD_MODE_ROLLOUT && writer) p.returns_out[prob] = G_ret;
+#ifdef OCD_STAMPS
+    OCD_STAMP(0);
+    if (p.debug && lane == 0)
+        for (int i = 0; i < 16; ++i) p.debug[(size_t)blockIdx.x * 16 + i] = st_acc[i];
+#endif
 }
 
 // ---------------------------------------------------------------- launch
@@ -469,11 +542,17 @@ static hipError_t launch_chunk(const KernelParams &p_in, hipStream_t st)
     constexpr int NC = HT / S;
     const int cap = 64 / (p.K * NC);                            // trajectories per wavefront
     if (cap < 1) return hipErrorInvalidConfiguration;
-    int segs = p.segs_used > 0 ? p.segs_used : cap;
+    const long long simds = 4ll * (p.n_cus > 0 ? p.n_cus : 256);
+    // spread over the SIMDs first (as V_SEG does): a batch that fills fewer than one wavefront per SIMD at full
+    // packing runs with fewer trajectories per wavefront on more SIMDs
+    long long want = (p.n_problems + simds - 1) / simds;
+    int segs = p.segs_used > 0 ? p.segs_used : (int)(want < 1 ? 1 : (want > cap ? cap : want));
     segs = segs < 1 ? 1 : (segs > cap ? cap : segs);
     p.segs_used = segs;
     const unsigned blocks = (unsigned)((p.n_problems + segs - 1) / segs);
-    hipLaunchKernelGGL((mpc_chunk_kernel<HT, NO, L, S>), dim3(blocks), dim3(64), 0, st, p);
+    const bool lat = L > 0 && NO > 0 && !p.no_skips && !p.no_unify && !p.no_latency_build && (long long)blocks <= simds;
+    if (lat) hipLaunchKernelGGL((mpc_chunk_kernel<HT, NO, L, S, true>), dim3(blocks), dim3(64), 0, st, p);
+    else hipLaunchKernelGGL((mpc_chunk_kernel<HT, NO, L, S>), dim3(blocks), dim3(64), 0, st, p);
     return hipGetLastError();
 }
 

@@ -303,6 +303,163 @@ __device__ __forceinline__ float reward_state(const ocd_scenario_desc &d, const 
     return r;
 }
 
+// ---------------------------------------------------------------- reward, fence + at most ONE scripted car per lane
+// Precondition (WAVE-UNIFORM, proved by the caller with needs_collision1): no live lane is inside the collision box
+// of MORE THAN ONE scripted car; nc[j] marks the lanes inside car j's box.  The fence is evaluated for every lane
+// (it is exactly 0 with +-0 adjoints where needs_fence fails), the collision term for the lane's one car only: the
+// cars a lane is not near have col == 0 exactly with +-0 adjoints, so the evaluated car is the reduce_max, tied with
+// all others iff its own product is 0 (as in reward_one).  Same operations on the same values as reward_state, sums
+// that only skip +-0 terms: the full evaluation's result bit for bit, at 15 divisions and 4 exponentials per
+// lane-step instead of 17 + 6 per scripted car.  This is the common multi-feature case of the scenarios whose
+// fence region overlaps a car's collision box (replanning: x in (0.05, 0.08); merging: x in (0.1, 0.18)).
+template <int NO, int L, bool GRAD>
+__device__ __forceinline__ float reward_fc(const ocd_scenario_desc &d, const float (&w)[OCD_MAX_FEATURES],
+                                           float x, float y, float v, float sn, float cn,
+                                           const BumpGeom (&bg)[NO > 0 ? NO : 1], const bool (&nc)[NO > 0 ? NO : 1], Q4 &q,
+                                           const PkConsts &pkc)
+{
+    static_assert(L > 0 && NO > 0, "lane-feature reward only");
+    const float tgt = d.target_speed;
+    const float bound = 4.0f * (tgt * tgt);
+    const float vel = v * sn;
+    const float dv = vel - tgt;
+    const float sq = dv * dv;
+    const bool pass0 = sq <= bound;
+    const float phi0 = min_tf(sq, bound);
+
+    float rl[L], pl[L];
+    float pmin = 0.0f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const float diff = x - d.lane_center[l];
+        rl[l] = diff * -1.0f;
+        const float d2 = rl[l] * rl[l];
+        pl[l] = d2 * 10.0f;
+        pmin = (l == 0) ? pl[0] : min_tf(pmin, pl[l]);
+    }
+    int ntie_min = 0;
+#pragma unroll
+    for (int l = 0; l < L; ++l) ntie_min += (pl[l] == pmin) ? 1 : 0;
+
+    // the one scripted car this lane may be colliding with
+    BumpGeom g = bg[0];
+#pragma unroll
+    for (int j = 1; j < NO; ++j) {
+        g.cx = nc[j] ? bg[j].cx : g.cx; g.wx = nc[j] ? bg[j].wx : g.wx;
+        g.cy = nc[j] ? bg[j].cy : g.cy; g.wy = nc[j] ? bg[j].wy : g.wy;
+    }
+    // ---- the two bump units (x, y) two-wide: bump_fwd's operations (ocd_devmath.h: div2_, exp_le1_2) ----
+#ifdef OCD_NO_PACKED
+    const float znx = (x - g.cx) / g.wx, zny = (y - g.cy) / g.wy;
+#else
+    const v2f ZN = div2_(v2f{x - g.cx, y - g.cy}, v2f{g.wx, g.wy});
+    const float znx = ZN.x, zny = ZN.y;
+#endif
+    const bool condx = (znx * znx) < 1.0f, condy = (zny * zny) < 1.0f;
+    const float xcx = condx ? znx : 0.0f, xcy = condy ? zny : 0.0f;
+    const float ub1 = 1.0f - xcx * xcx, ub2 = 1.0f - xcy * xcy;
+    // ---- the two fence units two-wide: thr_fwd's operations on the possibly-active side ----
+    const bool side_p = x > d.fence_lo;
+    const float z = side_p ? x : -x;
+    const float xd = z - d.fence_lo;
+    const bool pos1 = xd > 0.0f;
+    const float uf1 = d.fence_shape * (pos1 ? xd : (0.0f + 0.01f));
+    const float xd2 = d.fence_width - xd;
+    const bool pos2 = xd2 > 0.0f;
+    const float uf2 = d.fence_shape * (pos2 ? xd2 : (0.0f + 0.01f));
+#ifdef OCD_NO_PACKED
+    const float mb1 = -1.0f / ub1, mb2 = -1.0f / ub2, mf1 = -1.0f / uf1, mf2 = -1.0f / uf2;
+    const float eb1 = exp_le1(mb1 + 1.0f), eb2 = exp_le1(mb2 + 1.0f), ef1 = exp_le1(mf1), ef2 = exp_le1(mf2);
+#else
+    const v2f UB = {ub1, ub2}, UF = {uf1, uf2};
+    const v2f MB = div2_(splat2(-1.0f), UB), MF = div2_(splat2(-1.0f), UF);
+    const v2f EB = exp_le1_2(MB + splat2(1.0f), pkc), EF = exp_le1_2(MF, pkc);
+    const float mb1 = MB.x, mb2 = MB.y, mf1 = MF.x, mf2 = MF.y, eb1 = EB.x, eb2 = EB.y, ef1 = EF.x, ef2 = EF.y;
+#endif
+    const float bxv = condx ? eb1 : 0.0f;
+    const float byv = condy ? eb2 : 0.0f;
+    const float pcol = bxv * byv;                  // the reduce_max: every other car's product is exactly 0
+    const float F1 = pos1 ? ef1 : 0.0f, F2 = pos2 ? ef2 : 0.0f;
+    const float den = F1 + F2;
+    const float Ssum = F1 / den;
+    const float ax = (x < 0.0f) ? -x : x;
+    const float pf = Ssum * ax;
+
+    float r = w[0] * phi0;
+#pragma unroll
+    for (int l = 0; l < L; ++l) r = r + w[1 + l] * pl[l];
+    const float w_min = w[L + 1], w_col = w[L + 2], w_f = w[L + 3];
+    r = r + w_min * pmin;
+    r = r + w_col * pcol;
+    r = r + w_f * pf;
+    if (!GRAD) return r;
+
+    const float g_sq = pass0 ? w[0] : 0.0f;
+    const float g_dv = (g_sq * 2.0f) * dv;
+    q.qv = g_dv * sn;
+    const float g_sn = g_dv * v;
+    q.qth = g_sn * cn;
+
+    float qx = 0.0f, qy = 0.0f;
+    const float min_share = inv_count(ntie_min) * w_min;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        float gl = w[1 + l];
+        gl = (pl[l] == pmin) ? (gl + min_share) : gl;
+        const float g_d2 = gl * 10.0f;
+        const float g_r = (g_d2 * 2.0f) * rl[l];
+        qx = qx + g_r * -1.0f;
+    }
+    // the evaluated car is among the maxima in both cases: alone (product > 0) or tied with all NO cars (product 0)
+    const float col_share = ((NO == 1) ? 1.0f : ((pcol == 0.0f) ? inv_count(NO) : 1.0f)) * w_col;
+    const float g_Ssum = w_f * ax;
+    const float g_ax = w_f * Ssum;
+#ifdef OCD_NO_PACKED
+    const float kb1 = (-mb1) / ub1, kb2 = (-mb2) / ub2, kf1 = (-mf1) / uf1, kf2 = (-mf2) / uf2;
+    // bump_bwd (without its head select: where cond is false the last select yields 0 whatever the chain computed)
+    const float gx_q = ((col_share * byv) * eb1) * kb1;
+    const float gx_xc = ((-gx_q) * 2.0f) * xcx;
+    const float gy_q = ((col_share * bxv) * eb2) * kb2;
+    const float gy_xc = ((-gy_q) * 2.0f) * xcy;
+    const float g_znx = condx ? gx_xc : 0.0f, g_zny = condy ? gy_xc : 0.0f;
+    const float qbx = g_znx / g.wx, qby = g_zny / g.wy;
+    const float q1 = g_Ssum / den, q2 = (-Ssum) / den;
+#else
+    const v2f KB = div2_(-MB, UB), KF = div2_(-MF, UF);
+    const float kf1 = KF.x, kf2 = KF.y;
+    v2f GXY;
+    {
+        const v2f B = {bxv, byv}, CS = splat2(col_share), XC = {xcx, xcy};
+        asm("v_pk_mul_f32 %[g], %[b], %[cs] op_sel:[1,0] op_sel_hi:[0,1]\n"     // (byv, bxv) * col_share
+            "v_pk_mul_f32 %[g], %[g], %[e]\n"
+            "v_pk_mul_f32 %[g], %[g], %[k]\n"
+            "v_pk_mul_f32 %[g], %[g], 2.0 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]\n"
+            "v_pk_mul_f32 %[g], %[g], %[xc]\n"
+            : [g] "=&v"(GXY) : [b] "v"(B), [cs] "v"(CS), [e] "v"(EB), [k] "v"(KB), [xc] "v"(XC));
+    }
+    const float g_znx = condx ? GXY.x : 0.0f, g_zny = condy ? GXY.y : 0.0f;
+    const v2f QB = div2_(v2f{g_znx, g_zny}, v2f{g.wx, g.wy});
+    const v2f QF = div2_(v2f{g_Ssum, -Ssum}, v2f{den, den});
+    const float qbx = QB.x, qby = QB.y, q1 = QF.x, q2 = QF.y;
+#endif
+    qx = qx + qbx;
+    qy = qy + qby;
+    // thr_bwd
+    const float g_den = g_Ssum * q2;
+    FTape t1, t2;
+    t1.pos = pos1; t1.m = mf1; t1.e = ef1; t1.u = uf1;
+    t2.pos = pos2; t2.m = mf2; t2.e = ef2; t2.u = uf2;
+    const float ga = f_bwd_gated(q1, d.fence_shape, t1, kf1);
+    const float gb = f_bwd_gated(g_den, d.fence_shape, t1, kf1);
+    const float gc = f_bwd_gated(g_den, d.fence_shape, t2, kf2);
+    const float g_z = (ga + gb) + (-gc);
+    qx = qx + (side_p ? g_z : -g_z);
+    const float sgn = (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f);
+    qx = qx + g_ax * sgn;
+    q.qx = qx; q.qy = qy;
+    return r;
+}
+
 // Lane-feature gradient factors of one trajectory (its weights are fixed for the whole episode): the chain
 //   g = w_l (+ w_min when lane l is the sole minimum) ; g_d2 = g * 10 ; (g_d2 * 2)
 // of the backward pass evaluated once, outside the SGD loop (same operations, same order, hoisted).

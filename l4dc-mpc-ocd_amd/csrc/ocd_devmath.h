@@ -121,7 +121,7 @@ __device__ __forceinline__ v2f div2_(v2f n, v2f d)
 
 // Constants of exp_le1_2, two per VGPR pair (a packed instruction picks the low or the high dword of a
 // source for both of its lanes through op_sel / op_sel_hi).  Built once per kernel and pinned in registers.
-struct PkConsts { v2f a, b, c, d, e, f; };
+struct PkConsts { v2f a, b, c, d, e; };
 
 __device__ __forceinline__ PkConsts pk_consts()
 {
@@ -131,8 +131,9 @@ __device__ __forceinline__ PkConsts pk_consts()
     k.c = v2f{2.12194440e-4f, 1.9875691500e-4f};              // ln2 (low part) | c5
     k.d = v2f{1.3981999507e-3f, 8.3334519073e-3f};            // c4 | c3
     k.e = v2f{4.1665795894e-2f, 1.6666665459e-1f};            // c2 | c1
-    k.f = v2f{5.0000001201e-1f, 0.0f};                        // c0 | -
-    asm volatile("" : "+v"(k.a), "+v"(k.b), "+v"(k.c), "+v"(k.d), "+v"(k.e), "+v"(k.f));   // keep, do not rematerialise
+    // (c0 = 5.0000001201e-1f rounds to exactly 0.5f: an inline constant of the instruction, no register)
+    static_assert(5.0000001201e-1f == 0.5f, "c0 is the inline constant 0.5");
+    asm volatile("" : "+v"(k.a), "+v"(k.b), "+v"(k.c), "+v"(k.d), "+v"(k.e));   // keep, do not rematerialise
     return k;
 }
 
@@ -151,12 +152,12 @@ __device__ __forceinline__ v2f exp_le1_2(v2f x, const PkConsts &k)
         "v_pk_fma_f32 %[p], %[p], %[r], %[D] op_sel:[0,0,1] op_sel_hi:[1,1,1]\n"   // p * r + c3
         "v_pk_fma_f32 %[p], %[p], %[r], %[E] op_sel_hi:[1,1,0]\n"                 // p * r + c2
         "v_pk_fma_f32 %[p], %[p], %[r], %[E] op_sel:[0,0,1] op_sel_hi:[1,1,1]\n"   // p * r + c1
-        "v_pk_fma_f32 %[p], %[p], %[r], %[F] op_sel_hi:[1,1,0]\n"                 // p * r + c0
+        "v_pk_fma_f32 %[p], %[p], %[r], 0.5 op_sel_hi:[1,1,0]\n"                  // p * r + c0 (= 0.5 exactly)
         "v_pk_mul_f32 %[e], %[r], %[r]\n"
         "v_pk_fma_f32 %[e], %[p], %[e], %[r]\n"
         "v_pk_add_f32 %[e], %[e], 1.0 op_sel_hi:[1,0]\n"
         : [n] "=&v"(n), [r] "=&v"(r), [p] "=&v"(p), [e] "=&v"(e)
-        : [xs] "v"(xs), [A] "v"(k.a), [B] "v"(k.b), [C] "v"(k.c), [D] "v"(k.d), [E] "v"(k.e), [F] "v"(k.f));
+        : [xs] "v"(xs), [A] "v"(k.a), [B] "v"(k.b), [C] "v"(k.c), [D] "v"(k.d), [E] "v"(k.e));
     v2f scale;
     scale.x = __int_as_float(((int32_t)n.x + 127) << 23);
     scale.y = __int_as_float(((int32_t)n.y + 127) << 23);

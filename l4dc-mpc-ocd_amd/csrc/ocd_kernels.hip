@@ -94,7 +94,7 @@ __host__ __device__ constexpr Geo geo_lds(int H)
 //   active" path, no has_col / has_f skips) and repairs the rare pass with a multi-feature lane afterwards.
 //   The diagnostics knobs no_feature_skips / no_unified_features select the LAT = false build.
 template <int HT, int NO, int L, int V, bool LEAF = false, bool LAT = false>
-__global__ void __launch_bounds__(V == V_SEG ? 64 : 64 * OCD_MAX_CTRL_INITS)
+__global__ void __launch_bounds__(V == V_SEG ? 64 : 64 * OCD_MAX_CTRL_INITS, 1)
 mpc_kernel(const KernelParams p)
 {
     static_assert(!LAT || V == V_ROW || V == V_SEG, "LAT is a V_ROW / V_SEG build");
@@ -438,33 +438,42 @@ mpc_kernel(const KernelParams p)
                 bool nc[NOA];
                 nc[0] = false;
                 const bool nf = needs_fence(d, xn);
-                unsigned long long mf = __builtin_amdgcn_ballot_w64(nf) & feat_mask, mc_any = 0ull, multi = 0ull;
+                // multi_f: some lane has the fence AND a car active; multi_c: some lane is inside two cars' boxes
+                unsigned long long mf = __builtin_amdgcn_ballot_w64(nf) & feat_mask, mc_any = 0ull, multi_f = 0ull, multi_c = 0ull;
 #pragma unroll
                 for (int j = 0; j < NO; ++j) {
                     const float dx = xn - bg[j].cx, dy = yn - bg[j].cy;
                     const bool ncx = __builtin_fabsf(dx) < wx1[j], ncy = __builtin_fabsf(dy) < wy1[j];
                     nc[j] = ncx && ncy;
                     const unsigned long long mj = __builtin_amdgcn_ballot_w64(ncx) & __builtin_amdgcn_ballot_w64(ncy) & feat_mask;
-                    multi |= (mj & (mf | mc_any));
+                    multi_f |= (mj & mf);
+                    multi_c |= (mj & mc_any);
                     mc_any |= mj;
                 }
                 const bool has_f = mf != 0ull, has_col = mc_any != 0ull;
                 const unsigned long long any_feat = mf | mc_any;
                 OCD_STAMP(4);                              // choice of the evaluation
                 if constexpr (LAT) {
+                    // one feature per lane, straight line; the pass with a multi-feature lane is repaired afterwards,
+                    // out of line (the shapes that run LAT builds -- one wavefront per SIMD at H <= 16 -- are the
+                    // scenarios whose fence region and collision boxes do not overlap: it is rare or impossible there)
                     r = reward_one<NO, L, GRAD, false, phi0_in_chain>(d, w, xn, yn, vn, sn, cn, bg, nc, nf, true, true, q, pkc, lgc, feat_mask);
                     OCD_STAMP(6); OCD_STAMP_COUNT(13);     // one feature per lane
-                    if (__builtin_expect(multi != 0ull, 0)) {
-                        r = reward_state<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, true, true);
-                        OCD_STAMP(5); OCD_STAMP_COUNT(12); // every feature
+                    if (__builtin_expect((multi_f | multi_c) != 0ull, 0)) {
+                        if (multi_c != 0ull) r = reward_state<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, true, true);
+                        else r = reward_fc<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, nc, q, pkc);
+                        OCD_STAMP(5); OCD_STAMP_COUNT(12); // every feature / fence + one car per lane
                     }
                 } else {
                     // (the diagnostics knobs enter as two wave-uniform masks: two scalar tests decide the path)
-                    const unsigned long long full_m = multi | force_full | (any_feat & force_full_any);
+                    const unsigned long long full_m = multi_c | force_full | (any_feat & force_full_any);
                     if (__builtin_expect((any_feat | force_full) != 0ull, 1)) {
                         if (__builtin_expect(full_m != 0ull, 0)) {
                             r = reward_state<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, true, true);
                             OCD_STAMP(5); OCD_STAMP_COUNT(12);     // every feature
+                        } else if (multi_f != 0ull) {
+                            r = reward_fc<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, nc, q, pkc);
+                            OCD_STAMP(5); OCD_STAMP_COUNT(12);     // fence + one car per lane
                         } else {
                             r = reward_one<NO, L, GRAD, true>(d, w, xn, yn, vn, sn, cn, bg, nc, nf, has_col, has_f, q, pkc, lgc, feat_mask);
                             OCD_STAMP(6); OCD_STAMP_COUNT(13);     // one feature per lane

@@ -2,7 +2,9 @@
 # rocprofv3 evidence for profiles/: per BASELINE config, one kernel-trace/stats run and three PMC passes
 # (FETCH_SIZE, WRITE_SIZE, SQ_*) of the SAME bench.py command, each in its own run (gpurun refuses
 # --pmc combined with the trace domains other than --kernel-trace).  Run ON THE GPU BOX from the repo root:
-#     bash tools/profile_round.sh r02 "2 3 4 5"
+#     bash tools/profile_round.sh r03 "2 3 4 5 4s 5s"
+# A workload token is a BASELINE config index, or <index>s = the share of rank 0 of an 8-way strong split of that
+# config run on this one GPU (bench.py --emulate-rank 0/8): 4s = 2 048 episodes at H=15, 5s = 4 096 at H=25.
 # Writes rocpd databases under gpurun_out/prof_<round>/ (scratch) and the condensed summaries
 # profiles/<round>_cfg<N>_rocprofv3.txt + profiles/pmc_counters.json (tracked).
 set -e -o pipefail
@@ -14,8 +16,10 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 SQ="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_ANY"
 for c in $CONFIGS; do
-    steps=30; [ "$c" -ge 4 ] && steps=6
-    args="bench.py --config $c --steps $steps --warmup 2 --no-extras --no-cpu-baseline"
+    n=${c%s}
+    steps=30; [ "$n" -ge 4 ] && steps=6
+    extra=""; [ "$c" != "$n" ] && { extra="--emulate-rank 0/8"; steps=20; }
+    args="bench.py --config $n $extra --steps $steps --warmup 2 --no-extras --no-cpu-baseline"
     cd /tmp
     rocprofv3 --kernel-trace --stats -d "$OUT/c${c}_stats" -o res -- python3 "$ROOT"/$args > "$OUT/c${c}_stats.log" 2>&1
     rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/c${c}_fetch" -o res -- python3 "$ROOT"/$args > "$OUT/c${c}_fetch.log" 2>&1
@@ -24,7 +28,7 @@ for c in $CONFIGS; do
     cd "$ROOT"
     python3 tools/rocprof_summary.py $(find "$OUT/c${c}_stats" "$OUT/c${c}_fetch" "$OUT/c${c}_write" "$OUT/c${c}_sq" -name "*.db" | sort) \
         > "$OUT/${ROUND}_cfg${c}_rocprofv3.txt"
-    echo "config $c profiled"
+    echo "workload $c profiled"
 done
 python3 tools/rocprof_summary.py --json "$ROUND" "$OUT" > "$OUT/pmc_counters.json"
 # the tracked copies (bench.py replays profiles/pmc_counters.json; the judge reads profiles/)

@@ -24,17 +24,24 @@ def main():
     ap.add_argument("--scan-mode", type=int, default=0)
     ap.add_argument("--segs", type=int, default=0)
     ap.add_argument("--no-skips", type=int, default=0)
+    ap.add_argument("--no-lat", type=int, default=0)
+    ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--pop", type=int, default=0, help="override the population (e.g. the share of one of 8 GPUs)")
     a = ap.parse_args()
     os.environ["OCD_HIP_LIB"] = os.path.join(ROOT, "l4dc-mpc-ocd_amd", "csrc", "libocd_hip_stamps.so")
     import torch
     from l4dc_mpc_ocd_amd import scenarios
     from l4dc_mpc_ocd_amd.engine import Engine
     scn, inits, cands = scenarios.baseline_config(a.config)
+    if a.pop:
+        cands = scn.candidate_weights(a.pop, seed=2000 + a.config)
     w32 = np.stack([scenarios.planner_weights_fp32(c) for c in cands])
     eng = Engine(scn, "cuda:0")
     eng.set_option("scan_mode", a.scan_mode)
     eng.set_option("segs_per_wave", a.segs)
     eng.set_option("no_feature_skips", a.no_skips)
+    eng.set_option("no_latency_build", a.no_lat)
+    eng.set_option("chunk_size", a.chunk)
     E = w32.shape[0] * inits.shape[0] * scn.desc.n_samples
     nw = E * scn.desc.n_ctrl_inits + 64
     buf = torch.zeros(nw * 16, dtype=torch.int64, device="cuda:0")
