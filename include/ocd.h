@@ -201,6 +201,23 @@ int32_t ocd_plan_batch(const ocd_scenario *scn,
                        int64_t B, void *hip_stream);
 
 /*
+ * ocd_plan_batch with the planning car's OWN current speed given apart from the state the plan starts from.
+ * The extra_inits control initialisations coast at friction * self.car.state[2] ** 2 (naive_planner.py:112-116):
+ * the speed of the car object, not of the `init_state` argument.  The two coincide whenever the planner is
+ * called from CarWorld.step (init_state = None), which is what ocd_plan_batch and the rollouts assume;
+ * generate_plan(init_state=<another state>) with extra_inits needs this entry point.
+ *   init_speed [B]  self.car.state[2] per problem (device pointer), or NULL = the ego speed in world_state
+ * Everything else as ocd_plan_batch.
+ */
+int32_t ocd_plan_batch_from(const ocd_scenario *scn,
+                            const float *world_state, const float *init_speed,
+                            const float *weights, int32_t weights_per_problem,
+                            const float *other_plans,
+                            float *plans_out, float *best_loss_out, int32_t *best_init_out,
+                            float *all_plans_out, float *all_losses_out,
+                            int64_t B, void *hip_stream);
+
+/*
  * Full receding-horizon episodes: for every (candidate p, init n, sample s)
  * with flat index e = (p*N + n)*S + s in [ep_begin, ep_end): reset the world,
  * then T times { optional teleport; score the PRE-step state with the

@@ -92,6 +92,8 @@ HIP_SYMBOLS = [
     ("ocd_scenario_set_leaf_value", C.c_int32, [_VP, _F, C.c_int32, _F, C.c_int32, _F, C.c_int32, _F, C.c_int32]),
     ("ocd_plan_batch", C.c_int32,
      [_VP, _VP, _VP, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, _VP]),
+    ("ocd_plan_batch_from", C.c_int32,
+     [_VP, _VP, _VP, _VP, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, _VP]),
     ("ocd_rollout_episodes", C.c_int32,
      [_VP, _VP, _VP, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _VP, _VP, _VP, _VP]),
     ("ocd_rollout_from_state", C.c_int32,

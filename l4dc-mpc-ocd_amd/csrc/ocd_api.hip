@@ -273,10 +273,10 @@ void ocd_scenario_destroy(ocd_scenario *scn)
     delete scn;
 }
 
-int32_t ocd_plan_batch(const ocd_scenario *scn, const float *world_state,
-                       const float *weights, int32_t weights_per_problem, const float *other_plans,
-                       float *plans_out, float *best_loss_out, int32_t *best_init_out,
-                       float *all_plans_out, float *all_losses_out, int64_t B, void *hip_stream)
+int32_t ocd_plan_batch_from(const ocd_scenario *scn, const float *world_state, const float *init_speed,
+                            const float *weights, int32_t weights_per_problem, const float *other_plans,
+                            float *plans_out, float *best_loss_out, int32_t *best_init_out,
+                            float *all_plans_out, float *all_losses_out, int64_t B, void *hip_stream)
 {
     if (!scn) return fail(OCD_ERR_INVALID_ARG, "scenario is NULL");
     if (B < 0) return fail(OCD_ERR_INVALID_ARG, "B = %lld < 0", (long long)B);
@@ -291,6 +291,7 @@ int32_t ocd_plan_batch(const ocd_scenario *scn, const float *world_state,
     p.mode = ocd::OCD_MODE_PLAN;
     p.T = 1;
     p.ego_states = world_state;
+    p.init_speed = init_speed;
     p.weights = weights;
     p.weights_per_problem = weights_per_problem;
     p.other_plans = other_plans;
@@ -301,6 +302,15 @@ int32_t ocd_plan_batch(const ocd_scenario *scn, const float *world_state,
     p.all_losses_out = all_losses_out;
     p.n_problems = B;
     return launch(scn, p, hip_stream);
+}
+
+int32_t ocd_plan_batch(const ocd_scenario *scn, const float *world_state,
+                       const float *weights, int32_t weights_per_problem, const float *other_plans,
+                       float *plans_out, float *best_loss_out, int32_t *best_init_out,
+                       float *all_plans_out, float *all_losses_out, int64_t B, void *hip_stream)
+{
+    return ocd_plan_batch_from(scn, world_state, nullptr, weights, weights_per_problem, other_plans, plans_out,
+                               best_loss_out, best_init_out, all_plans_out, all_losses_out, B, hip_stream);
 }
 
 static int32_t rollout_params(const ocd_scenario *scn, const float *init_states, const float *cand_weights,

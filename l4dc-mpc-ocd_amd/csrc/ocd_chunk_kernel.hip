@@ -189,7 +189,10 @@ mpc_chunk_kernel(const KernelParams p)
         // ---- control initialisation of this segment (naive_planner.py:107-116) ----
         float s0, c0;
         sincos_(eth, s0, c0);
-        const float a_coast = fr * (ev * ev);
+        // extra_inits coast at friction * self.car.state[2] ** 2 (naive_planner.py:114): the car's own speed, which
+        // a caller planning from a foreign init_state passes apart (ocd_plan_batch_from); else the state's ego speed
+        const float v_car = (p.init_speed != nullptr) ? p.init_speed[prob] : ev;
+        const float a_coast = fr * (v_car * v_car);
         const int k3 = kinit % 3;
         float ua[S], uw[S];
 #pragma unroll

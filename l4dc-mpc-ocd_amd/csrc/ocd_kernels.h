@@ -35,6 +35,7 @@ struct KernelParams {
     const float *ego_states;   // ROLLOUT: init_states [N,4];  PLAN / ROLLOUT-from-state: world_state [B,C,4]
     const float *weights;      // ROLLOUT: [P,D];  PLAN: [B,D] or [D]
     const float *other_plans;  // [C-1,H,2] or nullptr (constant-velocity model)
+    const float *init_speed;   // PLAN: [B] the car's own speed for the extra_inits (naive_planner.py:114) or nullptr
     float *returns_out;        // ROLLOUT [n]
     float *traj_out;           // ROLLOUT [n,T+1,C,4] or nullptr
     float *ctrl_out;           // ROLLOUT [n,T,2] or nullptr

@@ -296,7 +296,10 @@ mpc_kernel(const KernelParams p)
         // ---- this lane's control initialisation (naive_planner.py:107-116) ----
         float s0, c0;
         sincos_(eth, s0, c0);
-        const float a_coast = fr * (ev * ev);
+        // extra_inits coast at friction * self.car.state[2] ** 2 (naive_planner.py:114): the car's own speed, which
+        // a caller planning from a foreign init_state passes apart (ocd_plan_batch_from); else the state's ego speed
+        const float v_car = (p.init_speed != nullptr) ? p.init_speed[prob] : ev;
+        const float a_coast = fr * (v_car * v_car);
         const int k3 = kinit % 3;
         float ua = (kinit >= 3) ? a_coast : 0.0f;
         float uw = (k3 == 0) ? 0.0f : ((k3 == 1) ? -0.65f : 0.65f);
@@ -908,8 +911,9 @@ static int clampi(long long v, long long lo, long long hi) { return (int)(v < lo
 //     feature skips alone; K wavefronts meet once per control step);
 //   * V_SEG (single-wavefront workgroups spread evenly over the SIMDs, no workgroup barrier) while it gives
 //     at most one wavefront per SIMD, or up to four when it packs lanes as densely as V_LDS (K*H close to 64);
-//   * V_CHUNK once its wavefronts (S times the problems each) fill enough of the chip: from 3/4 of the SIMDs
-//     at H >= 20, where the O(H^2) recurrence work it removes dominates, one per SIMD at H >= 15, three below;
+//   * V_CHUNK once its wavefronts (S times the problems each, spread over the SIMDs first) beat the others: at
+//     H >= 20, where the O(H^2) recurrence work it removes dominates, whenever V_LDS would need more than one
+//     wavefront per SIMD; from one full-packed wavefront per SIMD at H >= 15, 4/5 of that below;
 //   * else V_LDS, densest packing at one lane per step, LDS latency hidden by the other wavefronts.
 // scan_mode 1..4 and segs_per_wave force the choice (tests, sweeps).
 template <int HT, int NO, int L>
@@ -935,10 +939,15 @@ static hipError_t launch_mpc(const KernelParams &p_in, hipStream_t st)
         const long long waves_seg = seg_cap ? ceil_div(n, seg_cap) : 0;
         const long long waves_lds = ceil_div(n, G.SEGS) * K;
         const long long waves_chunk = chunk ? ceil_div(n, 64 / (K * (H / chunk))) : 0;
-        const long long chunk_from = (H >= 20) ? (3 * simds) / 4 : ((H >= 15) ? simds : 3 * simds);
+        // (round-3 sweeps, tools/sweep_sizes.sh: with its wavefronts spread over the SIMDs first the chunked mapping wins
+        //  at H >= 20 as soon as V_LDS would put more than one wavefront on a SIMD, at H = 15 from one full-packed
+        //  wavefront per SIMD, at H = 10 from 4/5 of that -- 8 192 episodes of config 3's shape)
+        const long long chunk_from = (H >= 20) ? 0 : ((H >= 15) ? simds : (4 * simds) / 5);
+        const bool chunk_wins = chunk && waves_chunk >= chunk_from && waves_lds > simds;
         if (row_cap && n * K <= simds) variant = V_ROW;
-        else if (seg_cap && (waves_seg <= simds || (waves_seg * 20 <= waves_lds * 21 && waves_seg <= 4 * simds))) variant = V_SEG;
-        else if (chunk && waves_chunk >= chunk_from) variant = V_CHUNK;
+        else if (seg_cap && waves_seg <= simds) variant = V_SEG;
+        else if (chunk_wins) variant = V_CHUNK;
+        else if (seg_cap && waves_seg * 20 <= waves_lds * 21 && waves_seg <= 4 * simds) variant = V_SEG;
         else if (row_cap && ceil_div(n, row_cap) * K <= simds) variant = V_ROW;
     }
     if (variant == V_CHUNK) return launch_chunk_dispatch(H, NO, L, p, st, true, p.chunk_size, &chunk);

@@ -116,8 +116,9 @@ class Engine(DeviceOps):
 
     # ------------------------------------------------------------------ entry points
     def plan_batch(self, world_state, weights=None, other_plans="scenario", want_all: bool = False,
-                   to_numpy: bool = True) -> Dict[str, object]:
-        """NaivePlanner.generate_plan for a batch of world states [B, C, 4]."""
+                   to_numpy: bool = True, init_speed=None) -> Dict[str, object]:
+        """NaivePlanner.generate_plan for a batch of world states [B, C, 4].  init_speed [B]: the planning car's own
+        current speed where it differs from the state the plan starts from (extra_inits, naive_planner.py:114)."""
         d = self.desc
         ws = self._to_dev(world_state).reshape(-1, d.n_cars, 4)
         B = ws.shape[0]
@@ -135,8 +136,13 @@ class Engine(DeviceOps):
         best = torch.empty((B,), dtype=torch.int32, device=self.device)
         all_plans = torch.empty((B, K, H, 2), dtype=torch.float32, device=self.device) if want_all else None
         all_losses = torch.empty((B, K), dtype=torch.float32, device=self.device) if want_all else None
-        self._call(self.lib.ocd_plan_batch, self._h, _ptr(ws), _ptr(w), per, _ptr(op), _ptr(plans), _ptr(loss),
-                   _ptr(best), _ptr(all_plans), _ptr(all_losses), B, self._stream())
+        vs = None
+        if init_speed is not None:
+            vs = self._to_dev(init_speed).reshape(-1)
+            if vs.shape[0] != B:
+                raise ValueError(f"init_speed has {vs.shape[0]} entries for {B} world states")
+        self._call(self.lib.ocd_plan_batch_from, self._h, _ptr(ws), _ptr(vs), _ptr(w), per, _ptr(op), _ptr(plans),
+                   _ptr(loss), _ptr(best), _ptr(all_plans), _ptr(all_losses), B, self._stream())
         out = dict(plans=plans, best_loss=loss, best_init=best)
         if want_all:
             out.update(all_plans=all_plans, all_losses=all_losses)

@@ -79,8 +79,13 @@ class NaivePlanner(CarPlanner):
         """naive_planner.py:81-164.  Returns self.planned_controls (list of H Tensors of shape (2,))."""
         if use_lbfgs:
             raise NotImplementedError("use_lbfgs needs tensorflow_probability and is not on the accelerated path")
+        # the extra_inits coast at friction * self.car.state[2] ** 2 -- the CAR's speed, whatever init_state says (:114)
+        own_speed = None
+        if self.extra_inits and init_state is not None:
+            own_speed = np.asarray([np.asarray(self.car.state, dtype=np.float32)[2]], dtype=np.float32)
         out = self._engine().plan_batch(self._world_state(init_state)[None], self._weights(weights),
-                                        other_plans=self._other_plans(other_controls), want_all=True)
+                                        other_plans=self._other_plans(other_controls), want_all=True,
+                                        init_speed=own_speed)
         self.last_losses = out["all_losses"][0]
         self.last_best_init = int(out["best_init"][0])
         for control, val in zip(self.planned_controls, out["plans"][0]):

@@ -478,16 +478,23 @@ float ocd_oracle_mpc_reward(const ocd_scenario_desc *d, const float *ws, const f
 }
 
 /* ---- NaivePlanner.generate_plan (naive_planner.py:81-164) ---- */
+/* extra_inits reads the CAR's current speed, `self.car.state[2]` (naive_planner.py:114), not the speed of the
+ * init_state argument: they differ when generate_plan is called with a foreign init_state.  NULL: the world
+ * state's own ego speed (what CarWorld.step always gives). */
+static const float *g_init_speed = 0;
+void ocd_oracle_set_init_speed(const float *init_speed /* [B] or NULL */) { g_init_speed = init_speed; }
+
 static void plan_one(const ocd_scenario_desc *d, const float *ws, const float *w,
                      const float *other_plans, float *plan_out, float *best_loss, int32_t *best_init,
-                     float *all_plans /*[K,H,2] or NULL*/, float *all_losses /*[K] or NULL*/)
+                     float *all_plans /*[K,H,2] or NULL*/, float *all_losses /*[K] or NULL*/, const float *init_speed)
 {
     const int H = d->horizon, K = d->extra_inits ? 6 : 3;
     float oxy[MAXH][MAXO][2];
     predict_others(d, ws, other_plans, oxy);
     const float lr = d->learning_rate;
     const float turn = 0.65f;                       /* 5 * 0.13 */
-    const float a_coast = d->ego_friction * (ws[2] * ws[2]);  /* friction * state[2] ** 2 */
+    const float v_car = init_speed ? *init_speed : ws[2];
+    const float a_coast = d->ego_friction * (v_car * v_car);  /* friction * self.car.state[2] ** 2 */
     float u[MAXH * 2], g[MAXH * 2], best_u[MAXH * 2];
     float bl = 0.0f; int bi = 0;
     for (int k = 0; k < K; ++k) {
@@ -542,7 +549,7 @@ int32_t ocd_plan_batch_cpu(const ocd_scenario_desc *d, const float *world_state,
         plan_one(d, world_state + b * C * 4, w, other_plans, plans_out + b * H * 2,
                  best_loss_out ? best_loss_out + b : NULL, best_init_out ? best_init_out + b : NULL,
                  all_plans_out ? all_plans_out + b * K * H * 2 : NULL,
-                 all_losses_out ? all_losses_out + b * K : NULL);
+                 all_losses_out ? all_losses_out + b * K : NULL, g_init_speed ? g_init_speed + b : NULL);
     }
     return OCD_OK;
 }
@@ -578,7 +585,7 @@ static float run_steps(const ocd_scenario_desc *d, float *ws, const float *w_pla
         const float r = ocd_oracle_reward(d, ws, d->designer_weights, NULL, NULL);
         G = G + r;                               /* sample_reward = 0; sample_reward += ... */
         /* ego plans (world.py:102-104) */
-        plan_one(d, ws, w_plan, d->check_plans ? oplans : NULL, plan, NULL, NULL, NULL, NULL);
+        plan_one(d, ws, w_plan, d->check_plans ? oplans : NULL, plan, NULL, NULL, NULL, NULL, NULL);
         if (ctrl) { ctrl[2 * k] = plan[0]; ctrl[2 * k + 1] = plan[1]; }
         /* all cars step through the real dynamics (world.py:106-107) */
         float nxt[OCD_MAX_CARS * 4];

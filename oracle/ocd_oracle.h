@@ -56,6 +56,11 @@ float ocd_oracle_mpc_reward(const ocd_scenario_desc *d, const float *world_state
 void ocd_oracle_set_leaf_value(const float *grid0, int32_t n0, const float *grid1, int32_t n1,
                                const float *grid2, int32_t n2, const float *values, int32_t proj_kind);
 
+/* The planning car's own current speed per problem for the extra_inits control initialisations (naive_planner.py:114
+ * reads self.car.state[2], not the init_state argument); NULL (default): the world state's ego speed.  Applies to
+ * ocd_plan_batch_cpu; the pointer must stay valid until it is reset. */
+void ocd_oracle_set_init_speed(const float *init_speed);
+
 /* CPU twins of the device entry points of include/ocd.h (HOST pointers). */
 int32_t ocd_plan_batch_cpu(const ocd_scenario_desc *d,
                            const float *world_state,

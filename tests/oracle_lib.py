@@ -91,6 +91,8 @@ class Oracle:
         lib.ocd_rollout_episodes_cpu.restype = C.c_int32
         lib.ocd_rollout_episodes_cpu.argtypes = [_D, _F, _F, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                                  _F, _F, _F, C.c_int32, C.c_int32]
+        lib.ocd_oracle_set_init_speed.restype = None
+        lib.ocd_oracle_set_init_speed.argtypes = [_F]
         lib.ocd_oracle_set_leaf_value.restype = None
         lib.ocd_oracle_set_leaf_value.argtypes = [_F, C.c_int32, _F, C.c_int32, _F, C.c_int32, _F, C.c_int32]
         lib.ocd_rollout_from_state_cpu.restype = C.c_int32
@@ -156,7 +158,7 @@ class Oracle:
         return self.real(r), grad, traj
 
     # --- CPU twins of the device entry points ----------------------------
-    def plan_batch(self, desc, world_state, weights, other_plans=None, n_threads=0):
+    def plan_batch(self, desc, world_state, weights, other_plans=None, n_threads=0, init_speed=None):
         ws = np.ascontiguousarray(world_state, dtype=self.real)
         C_, H, K = desc.n_cars, desc.horizon, desc.n_ctrl_inits
         ws = ws.reshape(-1, C_, 4)
@@ -169,8 +171,14 @@ class Oracle:
         best = np.zeros(B, dtype=np.int32)
         all_plans = np.zeros((B, K, H, 2), dtype=self.real)
         all_losses = np.zeros((B, K), dtype=self.real)
-        st = self.lib.ocd_plan_batch_cpu(self._d(desc), self._fp(ws), self._fp(w), per, self._fp(op), self._fp(plans), self._fp(loss),
-                                         _ip(best), self._fp(all_plans), self._fp(all_losses), B, n_threads)
+        vs = None if init_speed is None else np.ascontiguousarray(init_speed, dtype=self.real).reshape(-1)
+        assert vs is None or vs.shape[0] == B
+        self.lib.ocd_oracle_set_init_speed(self._fp(vs))
+        try:
+            st = self.lib.ocd_plan_batch_cpu(self._d(desc), self._fp(ws), self._fp(w), per, self._fp(op), self._fp(plans),
+                                             self._fp(loss), _ip(best), self._fp(all_plans), self._fp(all_losses), B, n_threads)
+        finally:
+            self.lib.ocd_oracle_set_init_speed(None)
         if st != 0:
             raise RuntimeError(f"ocd_plan_batch_cpu -> {st}")
         return dict(plans=plans, best_loss=loss, best_init=best, all_plans=all_plans, all_losses=all_losses)

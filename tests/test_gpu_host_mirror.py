@@ -296,3 +296,20 @@ def test_leaf_evaluation_through_the_mirror(hip, oracle):
     assert not same(np.stack(plain), np.stack(plan))               # the terminal value changes the plan
     with pytest.raises(NotImplementedError):
         NaivePlanner(world, car, horizon=5, leaf_evaluation=lambda ws, u: 0.0)
+
+
+def test_generate_plan_from_a_foreign_state_uses_the_cars_own_speed(hip, oracle):
+    """naive_planner.py:112-116: with extra_inits the coasting initialisations use friction * self.car.state[2] ** 2,
+    the CAR's current speed, even when generate_plan is asked to plan from another init_state."""
+    car, world, _ = finite_horizon_env(horizon=6, extra_inits=True)
+    planner = NaivePlanner(world, car, horizon=6, n_iter=25, extra_inits=True)
+    own = np.asarray(car.state, dtype=np.float32)
+    state = [np.asarray(s, dtype=np.float32).copy() for s in world.state]
+    state[car.index][2] = own[2] + np.float32(0.6)             # plan from a faster state than the car is in
+    plan = planner.generate_plan(state)
+    d = planner._engine().desc
+    ref = oracle.plan_batch(d, np.stack(state)[None], car.weights.astype(np.float32), init_speed=own[2:3])
+    assert same(np.stack(plan), ref["plans"][0]) and planner.last_best_init == int(ref["best_init"][0])
+    assert same(planner.last_losses, ref["all_losses"][0])
+    naive = oracle.plan_batch(d, np.stack(state)[None], car.weights.astype(np.float32))     # the state's own speed instead
+    assert not same(naive["all_losses"][0][3:], ref["all_losses"][0][3:])

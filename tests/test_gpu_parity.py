@@ -126,6 +126,28 @@ def test_plan_batch_bitwise(oracle, eng_factory, name, H, extra, n_iter):
     assert np.all(np.isfinite(out["plans"]))
 
 
+@pytest.mark.parametrize("name,H,mode", [("finite_horizon", 6, 0), ("local_opt", 10, 0), ("local_opt", 10, 4), ("finite_horizon", 6, 1)])
+def test_extra_inits_coast_at_the_cars_own_speed(oracle, eng_factory, name, H, mode):
+    """naive_planner.py:114: the extra initialisations use friction * self.car.state[2] ** 2 -- the car object's
+    speed, not the init_state argument's.  ocd_plan_batch_from takes that speed apart from the world state."""
+    scn = scenarios.SCENARIOS[name](horizon=H, n_iter=30, extra_inits=True)
+    eng = eng_factory(scn)
+    eng.set_option("scan_mode", mode)
+    B = 21
+    ws = _world_states(scn, B, seed=3 * H)
+    w = np.stack([scenarios.planner_weights_fp32(c) for c in scn.candidate_weights(B, seed=H + 2)])
+    own = (ws[:, 0, 2] + np.random.default_rng(H).uniform(0.2, 0.8, B)).astype(np.float32)
+    out = eng.plan_batch(ws, w, want_all=True, init_speed=own)
+    ref = oracle.plan_batch(scn.desc, ws, w, other_plans=scn.other_plans(), init_speed=own)
+    assert_bitwise(out["all_plans"], ref["all_plans"], "all_plans")
+    assert_bitwise(out["all_losses"], ref["all_losses"], "all_losses")
+    assert np.array_equal(out["best_init"], ref["best_init"])
+    same_speed = eng.plan_batch(ws, w, want_all=True)
+    assert_bitwise(same_speed["all_plans"][:, :3], out["all_plans"][:, :3], "the three plain initialisations do not change")
+    assert not np.array_equal(same_speed["all_plans"][:, 3:], out["all_plans"][:, 3:])
+    assert_bitwise(eng.plan_batch(ws, w, want_all=True, init_speed=ws[:, 0, 2])["all_plans"], same_speed["all_plans"], "own speed == state speed")
+
+
 def test_plan_batch_shared_weights_and_single_problem(oracle, eng_factory):
     scn = scenarios.finite_horizon(horizon=5, n_iter=30)
     eng = eng_factory(scn)
