@@ -59,8 +59,18 @@ typedef enum ocd_reward_kind {
      * (interact_drive/planner/tests/targetSpeedRewardMaximizerCar.py:49-57);
      * only used to pin the planner against the reference's own known-answer
      * tests (interact_drive/planner/tests/test_naivePlanner.py:21-63). */
-    OCD_REWARD_TARGET_SPEED = 1
+    OCD_REWARD_TARGET_SPEED = 1,
+    /* LinearTargetSpeedPlannerCar (interact_drive/reward_design/tests/linearTargetSpeedPlannerCar.py:11-44):
+     * D = 2 features [v, (v - target_speed)^2], r = w_0 * v + w_1 * (v - target)^2 with the LinearRewardCar
+     * weights.  The planning car of the reference's inverse-optimal-control tests
+     * (reward_design/tests/test_first_order_ioc.py:29-60: weights (2, -1), target 0, v = 1, friction 0 "leads to
+     * zero controls"): the last planner known answer the reference holds.  n_lanes is ignored (0). */
+    OCD_REWARD_LINEAR_TARGET_SPEED = 2
 } ocd_reward_kind;
+
+/* Number of reward features D (the length of a weight vector) of a descriptor's reward kind. */
+#define OCD_N_FEATURES(reward_kind, n_lanes) \
+    ((reward_kind) == OCD_REWARD_LANE_FEATURES ? (n_lanes) + 4 : ((reward_kind) == OCD_REWARD_LINEAR_TARGET_SPEED ? 2 : 0))
 
 /*
  * Static description of one driving scenario: everything the reference's

@@ -29,6 +29,7 @@ OCD_ERR_NO_DEVICE = -4
 
 OCD_REWARD_LANE_FEATURES = 0
 OCD_REWARD_TARGET_SPEED = 1
+OCD_REWARD_LINEAR_TARGET_SPEED = 2
 
 
 class ScenarioDesc(C.Structure):
@@ -71,7 +72,9 @@ class ScenarioDesc(C.Structure):
 
     @property
     def n_features(self) -> int:
-        return self.n_lanes + 4 if self.reward_kind == OCD_REWARD_LANE_FEATURES else 0
+        if self.reward_kind == OCD_REWARD_LANE_FEATURES:
+            return self.n_lanes + 4
+        return 2 if self.reward_kind == OCD_REWARD_LINEAR_TARGET_SPEED else 0
 
     @property
     def n_ctrl_inits(self) -> int:

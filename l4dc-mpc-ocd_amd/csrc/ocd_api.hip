@@ -67,7 +67,8 @@ int32_t validate(const ocd_scenario_desc *d)
     if (!d) return fail(OCD_ERR_INVALID_ARG, "descriptor is NULL");
     if (d->abi_version != OCD_ABI_VERSION)
         return fail(OCD_ERR_INVALID_ARG, "descriptor abi_version %d != %d", d->abi_version, OCD_ABI_VERSION);
-    if (d->reward_kind != OCD_REWARD_LANE_FEATURES && d->reward_kind != OCD_REWARD_TARGET_SPEED)
+    if (d->reward_kind != OCD_REWARD_LANE_FEATURES && d->reward_kind != OCD_REWARD_TARGET_SPEED &&
+        d->reward_kind != OCD_REWARD_LINEAR_TARGET_SPEED)
         return fail(OCD_ERR_INVALID_ARG, "unknown reward_kind %d", d->reward_kind);
     if (d->n_cars < 1 || d->n_cars > OCD_MAX_CARS) return fail(OCD_ERR_INVALID_ARG, "n_cars %d out of [1,%d]", d->n_cars, OCD_MAX_CARS);
     if (d->n_lanes < 0 || d->n_lanes > OCD_MAX_LANES) return fail(OCD_ERR_INVALID_ARG, "n_lanes %d out of [0,%d]", d->n_lanes, OCD_MAX_LANES);
@@ -90,6 +91,13 @@ int32_t validate(const ocd_scenario_desc *d)
     if (d->reward_kind == OCD_REWARD_LANE_FEATURES && !(d->fence_lo >= 0.0f && d->fence_width > 0.0f))
         return fail(OCD_ERR_INVALID_ARG, "fence_lo must be >= 0 and fence_width > 0 (0.05*num_lanes - 0.05, 0.05)");
     return OCD_OK;
+}
+
+// the kernels' template parameter L (ocd_device.h: feat_dim)
+int kernel_L(const ocd_scenario_desc &d)
+{
+    if (d.reward_kind == OCD_REWARD_LANE_FEATURES) return d.n_lanes;
+    return d.reward_kind == OCD_REWARD_LINEAR_TARGET_SPEED ? -1 : 0;
 }
 
 int32_t need_device()
@@ -164,7 +172,7 @@ int32_t launch(const ocd_scenario *scn, ocd::KernelParams &p, void *hip_stream)
     p.debug = g_stamp_buf;
 #endif
     bool supported = false;
-    const int L = scn->desc.reward_kind == OCD_REWARD_LANE_FEATURES ? scn->desc.n_lanes : 0;
+    const int L = kernel_L(scn->desc);
     hipError_t e = ocd::launch_mpc_dispatch(scn->desc.horizon, scn->desc.n_cars - 1, L, p, (hipStream_t)hip_stream, &supported);
     if (!supported)
         return fail(OCD_ERR_UNSUPPORTED, "no compiled kernel for horizon %d with %d scripted cars and %d lanes (see OCD_PAIR_TABLE)",
@@ -257,7 +265,7 @@ int32_t ocd_scenario_create(const ocd_scenario_desc *desc, ocd_scenario **out)
     if (!s) return fail(OCD_ERR_INVALID_ARG, "out of memory");
     s->desc = *desc;
     s->K = desc->extra_inits ? 6 : 3;
-    s->D = desc->n_lanes + 4;
+    s->D = OCD_N_FEATURES(desc->reward_kind, desc->n_lanes);
     for (int i = 0; i < OCD_MAX_DEVICES; ++i) { s->dev_plans[i] = nullptr; s->dev_leaf[i] = nullptr; s->n_cus[i] = 0; }
     *out = s;
     return OCD_OK;
@@ -282,8 +290,8 @@ int32_t ocd_plan_batch_from(const ocd_scenario *scn, const float *world_state, c
     if (B < 0) return fail(OCD_ERR_INVALID_ARG, "B = %lld < 0", (long long)B);
     if (B == 0) return OCD_OK;
     if (!world_state || !plans_out) return fail(OCD_ERR_INVALID_ARG, "world_state / plans_out is NULL");
-    if (scn->desc.reward_kind == OCD_REWARD_LANE_FEATURES && !weights)
-        return fail(OCD_ERR_INVALID_ARG, "weights is NULL for a lane-feature reward");
+    if (scn->desc.reward_kind != OCD_REWARD_TARGET_SPEED && !weights)
+        return fail(OCD_ERR_INVALID_ARG, "weights is NULL for a weighted-feature reward");
     int32_t st = need_device();
     if (st != OCD_OK) return st;
     ocd::KernelParams p;
@@ -324,8 +332,8 @@ static int32_t rollout_params(const ocd_scenario *scn, const float *init_states,
     if (ep_begin < 0 || ep_end < ep_begin || ep_end > E)
         return fail(OCD_ERR_INVALID_ARG, "episode range [%lld, %lld) outside [0, %lld)", (long long)ep_begin, (long long)ep_end, (long long)E);
     if (!init_states || !returns_out) return fail(OCD_ERR_INVALID_ARG, "init_states / returns_out is NULL");
-    if (scn->desc.reward_kind == OCD_REWARD_LANE_FEATURES && !cand_weights)
-        return fail(OCD_ERR_INVALID_ARG, "cand_weights is NULL for a lane-feature reward");
+    if (scn->desc.reward_kind != OCD_REWARD_TARGET_SPEED && !cand_weights)
+        return fail(OCD_ERR_INVALID_ARG, "cand_weights is NULL for a weighted-feature reward");
     base_params(scn, p);
     p.mode = ocd::OCD_MODE_ROLLOUT;
     p.ego_states = init_states;
@@ -408,8 +416,8 @@ int32_t ocd_rollout_from_state(const ocd_scenario *scn, const float *world_state
     if (sample < 0 || sample >= OCD_MAX_SAMPLES) return fail(OCD_ERR_INVALID_ARG, "sample %d out of [0,%d)", sample, OCD_MAX_SAMPLES);
     if (B == 0) return OCD_OK;
     if (!world_state || !returns_out) return fail(OCD_ERR_INVALID_ARG, "world_state / returns_out is NULL");
-    if (scn->desc.reward_kind == OCD_REWARD_LANE_FEATURES && !weights)
-        return fail(OCD_ERR_INVALID_ARG, "weights is NULL for a lane-feature reward");
+    if (scn->desc.reward_kind != OCD_REWARD_TARGET_SPEED && !weights)
+        return fail(OCD_ERR_INVALID_ARG, "weights is NULL for a weighted-feature reward");
     int32_t st = need_device();
     if (st != OCD_OK) return st;
     const float *plans = nullptr;
@@ -444,8 +452,8 @@ int32_t ocd_mpc_reward_batch(const ocd_scenario *scn, const float *world_state,
     if (B < 0) return fail(OCD_ERR_INVALID_ARG, "B = %lld < 0", (long long)B);
     if (B == 0) return OCD_OK;
     if (!world_state || !controls) return fail(OCD_ERR_INVALID_ARG, "world_state / controls is NULL");
-    if (scn->desc.reward_kind == OCD_REWARD_LANE_FEATURES && !weights)
-        return fail(OCD_ERR_INVALID_ARG, "weights is NULL for a lane-feature reward");
+    if (scn->desc.reward_kind != OCD_REWARD_TARGET_SPEED && !weights)
+        return fail(OCD_ERR_INVALID_ARG, "weights is NULL for a weighted-feature reward");
     int32_t st = need_device();
     if (st != OCD_OK) return st;
     ocd::KernelParams p;
@@ -458,7 +466,7 @@ int32_t ocd_mpc_reward_batch(const ocd_scenario *scn, const float *world_state,
     p.other_plans = other_plans;
     p.n_problems = B;
     bool supported = false;
-    const int L = scn->desc.reward_kind == OCD_REWARD_LANE_FEATURES ? scn->desc.n_lanes : 0;
+    const int L = kernel_L(scn->desc);
     hipError_t e = ocd::launch_objective(scn->desc.n_cars - 1, L, p, controls, reward_out, grad_out, traj_out,
                                          (hipStream_t)hip_stream, &supported);
     if (!supported) return fail(OCD_ERR_UNSUPPORTED, "objective kernel: %d scripted cars, %d lanes", scn->desc.n_cars - 1, L);
@@ -486,7 +494,7 @@ int32_t ocd_reward_batch(const ocd_scenario *scn, const float *world_state, cons
     if (B < 0) return fail(OCD_ERR_INVALID_ARG, "B < 0");
     if (B == 0) return OCD_OK;
     if (!world_state) return fail(OCD_ERR_INVALID_ARG, "world_state is NULL");
-    if (scn->desc.reward_kind == OCD_REWARD_LANE_FEATURES && !weights)
+    if (scn->desc.reward_kind != OCD_REWARD_TARGET_SPEED && !weights)
         return fail(OCD_ERR_INVALID_ARG, "weights is NULL");
     int32_t st = need_device();
     if (st != OCD_OK) return st;
@@ -496,7 +504,7 @@ int32_t ocd_reward_batch(const ocd_scenario *scn, const float *world_state, cons
     p.weights = weights;
     p.n_problems = B;
     bool supported = false;
-    const int L = scn->desc.reward_kind == OCD_REWARD_LANE_FEATURES ? scn->desc.n_lanes : 0;
+    const int L = kernel_L(scn->desc);
     hipError_t e = ocd::launch_reward(scn->desc.n_cars - 1, L, p, feats_out, reward_out, (hipStream_t)hip_stream, &supported);
     if (!supported) return fail(OCD_ERR_UNSUPPORTED, "reward kernel: %d scripted cars, %d lanes", scn->desc.n_cars - 1, L);
     if (e != hipSuccess) return hip_fail(e, "reward_kernel launch");

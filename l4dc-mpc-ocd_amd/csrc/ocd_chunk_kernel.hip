@@ -45,7 +45,7 @@ mpc_chunk_kernel(const KernelParams p)
     constexpr int NC = HT / S;                                 // lanes per (trajectory, initialisation)
     constexpr int NOA = NO > 0 ? NO : 1;
     constexpr bool lane_feats = L > 0;
-    constexpr int D = L > 0 ? L + 4 : 0;
+    constexpr int D = feat_dim(L);
     const ocd_scenario_desc &d = p.d;
     const int K = p.K;
     const int lane = threadIdx.x & 63;

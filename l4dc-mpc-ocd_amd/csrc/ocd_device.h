@@ -148,6 +148,10 @@ __device__ __forceinline__ BumpGeom bump_geom(float ox, float oy, float hx, floa
 
 struct Q4 { float qx, qy, qv, qth; };
 
+// The kernels' template parameter L: > 0 = lane-feature reward with L lanes, 0 = target-speed test reward,
+// -1 = linear target-speed reward.  Number of features / weights of a reward:
+__host__ __device__ constexpr int feat_dim(int L) { return L > 0 ? L + 4 : (L < 0 ? 2 : 0); }
+
 // 1.0f / (float)n for a tie count n in [1, 4]: the correctly rounded quotients as constants
 __device__ __forceinline__ float inv_count(int n)
 {
@@ -193,6 +197,15 @@ __device__ __forceinline__ float reward_state(const ocd_scenario_desc &d, const 
         const float sq = dv * dv;
         if (GRAD) { q.qx = 0.0f; q.qy = 0.0f; q.qth = 0.0f; q.qv = (-1.0f * 2.0f) * dv; }
         return 0.0f - sq;
+    }
+    if (L < 0) {                                   // OCD_REWARD_LINEAR_TARGET_SPEED: w . [v, (v - target)^2]
+        const float dv = v - d.target_speed;       // (linearTargetSpeedPlannerCar.py:36-44)
+        const float sq = dv * dv;
+        float r = w[0] * v;
+        r = r + w[1] * sq;
+        if (feats) { feats[0] = v; feats[1] = sq; }
+        if (GRAD) { q.qx = 0.0f; q.qy = 0.0f; q.qth = 0.0f; q.qv = w[0] + (w[1] * 2.0f) * dv; }
+        return r;
     }
     constexpr int NOA = NO > 0 ? NO : 1;
     const float tgt = d.target_speed;

@@ -80,9 +80,11 @@ struct KernelParams {
     X(5, 2, 3) X(10, 2, 3) X(25, 2, 3)
 
 // (scripted cars NO, lanes L) pairs: generic planner kernel, reward kernel, objective kernel.
-// L = 0 is the target-speed test reward (any number of cars: the others do not enter it).
+// L = 0 is the target-speed test reward, L = -1 the linear target-speed reward (any number of cars: the others
+// do not enter either).
 #define OCD_PAIR_TABLE(X)                                                                     \
     X(0, 0) X(1, 0) X(2, 0) X(3, 0)                                                           \
+    X(0, -1) X(1, -1)                                                                         \
     X(1, 1) X(1, 2) X(1, 3) X(1, 4)                                                           \
     X(2, 1) X(2, 2) X(2, 3) X(2, 4)                                                           \
     X(3, 1) X(3, 2) X(3, 3) X(3, 4)

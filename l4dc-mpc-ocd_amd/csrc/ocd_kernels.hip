@@ -167,7 +167,7 @@ mpc_kernel(const KernelParams p)
     const long long prob = row_live ? prob_raw : (p.n_problems - 1); // parked lanes shadow a real problem
 
     const float dt = d.dt, dt2 = d.dt_sq, fr = d.ego_friction, lr = d.learning_rate;
-    constexpr int D = L > 0 ? L + 4 : 0;
+    constexpr int D = feat_dim(L);
 
     // ---- problem inputs -------------------------------------------------
     float ex, ey, ev, eth;                    // ego state
@@ -748,7 +748,7 @@ __global__ void reward_kernel(const KernelParams p, float *feats_out, float *rew
     const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= p.n_problems) return;
     const ocd_scenario_desc &d = p.d;
-    constexpr int D = L > 0 ? L + 4 : 0;
+    constexpr int D = feat_dim(L);
     const float *ws = p.ego_states + b * (NO + 1) * 4;
     float w[OCD_MAX_FEATURES];
 #pragma unroll
@@ -776,7 +776,7 @@ __global__ void objective_kernel(const KernelParams p, const float *controls, fl
     const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= p.n_problems) return;
     const ocd_scenario_desc &d = p.d;
-    constexpr int D = L > 0 ? L + 4 : 0;
+    constexpr int D = feat_dim(L);
     const int H = d.horizon;
     const float dt = d.dt, dt2 = d.dt_sq, fr = d.ego_friction;
     const float *ws = p.ego_states + b * (NO + 1) * 4;

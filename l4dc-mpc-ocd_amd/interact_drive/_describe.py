@@ -23,8 +23,8 @@ def describe(world, car, horizon: int, learning_rate: float = 0.1, n_iter: int =
     kind = getattr(car, "_ocd_reward_kind", None)
     if kind is None:
         raise NotImplementedError(
-            f"{type(car).__name__}: only ThreeLaneTestCar-style lane features and the target-speed test "
-            "reward are compiled for the GPU planner")
+            f"{type(car).__name__}: only ThreeLaneTestCar-style lane features and the two target-speed test "
+            "rewards are compiled for the GPU planner")
     d = abi.ScenarioDesc()
     d.abi_version = abi.OCD_ABI_VERSION
     d.reward_kind = kind
@@ -94,11 +94,11 @@ def describe(world, car, horizon: int, learning_rate: float = 0.1, n_iter: int =
             d.other_default[j][0], d.other_default[j][1] = float(other.control[0]), float(other.control[1])
         else:
             raise NotImplementedError(f"{type(other).__name__}: scripted cars must be FixedControl/Velocity/PlanCar")
-    if designer_weights is not None and kind == abi.OCD_REWARD_LANE_FEATURES:
+    if designer_weights is not None and kind != abi.OCD_REWARD_TARGET_SPEED:
         # only episode scoring reads these (mpc_ord.py:99); plans and rewards take weights per call
         w = np.asarray(designer_weights, dtype=np.float32)
-        if w.shape[0] != d.n_lanes + 4:
-            raise ValueError(f"weights has {w.shape[0]} entries, the car has {d.n_lanes + 4} features")
+        if w.shape[0] != d.n_features:
+            raise ValueError(f"weights has {w.shape[0]} entries, the car has {d.n_features} features")
         for i, v in enumerate(w):
             d.designer_weights[i] = v
     return d

@@ -342,6 +342,23 @@ def target_speed_kat(horizon: int, n_iter: int, learning_rate: float, friction: 
     return Scenario("target_speed_kat", d, None, None, default_init=np.array([0., 0., 1., _PI_2]))
 
 
+def linear_target_speed(horizon: int = 5, n_iter: int = 10, learning_rate: float = 5.0, friction: float = 0.0,
+                        target_speed: float = 0.0, weights=(2.0, -1.0), episode_len: int = 6) -> Scenario:
+    """The single-car world of the reference's inverse-optimal-control tests
+    (reward_design/tests/test_first_order_ioc.py:29-60, tests/linearTargetSpeedPlannerCar.py): features
+    [v, (v - target)^2], weights (2, -1) normalised by LinearRewardCar, start (0, 0, 1, pi/2)."""
+    d = _base_desc(horizon, n_iter, False, episode_len=episode_len)
+    d.reward_kind = abi.OCD_REWARD_LINEAR_TARGET_SPEED
+    d.n_cars = 1
+    d.n_lanes = 0
+    d.learning_rate = learning_rate
+    d.ego_friction = friction
+    d.target_speed = target_speed
+    raw = np.asarray(weights, dtype=np.float32)                  # tf.constant([2., -1.], dtype=tf.float32)
+    _set_designer(d, designer_weights_fp32(raw, raw_dtype=np.float32))
+    return Scenario("linear_target_speed", d, None, raw, default_init=np.array([0., 0., 1., _PI_2]), car_weights=raw)
+
+
 SCENARIOS = {
     "finite_horizon": finite_horizon,
     "local_opt": local_opt,

@@ -200,6 +200,17 @@ static float reward_state(const ocd_scenario_desc *d, const float *w,
         if (q) { q->qx = 0.0f; q->qy = 0.0f; q->qth = 0.0f; q->qv = (-1.0f * 2.0f) * dv; }
         return 0.0f - sq;
     }
+    if (d->reward_kind == OCD_REWARD_LINEAR_TARGET_SPEED) {
+        /* features = stack([velocity, (velocity - target) ** 2]); reward = reduce_sum(weights * features)
+         * (linearTargetSpeedPlannerCar.py:36-44, linear_reward_car.py:49-55) */
+        const float dv = v - d->target_speed;
+        const float sq = dv * dv;
+        float r = w[0] * v;
+        r = r + w[1] * sq;
+        if (feats) { feats[0] = v; feats[1] = sq; }
+        if (q) { q->qx = 0.0f; q->qy = 0.0f; q->qth = 0.0f; q->qv = w[0] + (w[1] * 2.0f) * dv; }
+        return r;
+    }
     const int L = d->n_lanes, D = L + 4, NO = d->n_cars - 1;
     float phi[OCD_MAX_FEATURES];
 
@@ -538,7 +549,7 @@ int32_t ocd_plan_batch_cpu(const ocd_scenario_desc *d, const float *world_state,
                            int64_t B, int32_t n_threads)
 {
     if (!check_desc(d) || !world_state || !plans_out || B < 0) return OCD_ERR_INVALID_ARG;
-    const int C = d->n_cars, H = d->horizon, D = d->n_lanes + 4, K = d->extra_inits ? 6 : 3;
+    const int C = d->n_cars, H = d->horizon, D = OCD_N_FEATURES(d->reward_kind, d->n_lanes), K = d->extra_inits ? 6 : 3;
     (void)n_threads;
 #ifdef _OPENMP
     const int nt = n_threads > 0 ? n_threads : omp_get_max_threads();
@@ -626,7 +637,7 @@ int32_t ocd_rollout_from_state_cpu(const ocd_scenario_desc *d, const float *worl
                                    float *returns_out, float *traj_out, float *ctrl_out, int64_t B)
 {
     if (!check_desc(d) || !world_state || !returns_out || B < 0 || n_steps < 0) return OCD_ERR_INVALID_ARG;
-    const int C = d->n_cars, D = d->n_lanes + 4;
+    const int C = d->n_cars, D = OCD_N_FEATURES(d->reward_kind, d->n_lanes);
     for (int64_t b = 0; b < B; ++b) {
         float ws[OCD_MAX_CARS * 4];
         memcpy(ws, world_state + b * C * 4, sizeof(float) * C * 4);
@@ -647,8 +658,8 @@ int32_t ocd_rollout_episodes_cpu(const ocd_scenario_desc *d, const float *init_s
     if (!check_desc(d) || !init_states || !returns_out) return OCD_ERR_INVALID_ARG;
     const int64_t S = d->n_samples, E = P * N * S;
     if (ep_begin < 0 || ep_end < ep_begin || ep_end > E) return OCD_ERR_INVALID_ARG;
-    if (d->reward_kind == OCD_REWARD_LANE_FEATURES && !cand_weights) return OCD_ERR_INVALID_ARG;
-    const int C = d->n_cars, T = d->episode_len, D = d->n_lanes + 4;
+    if (d->reward_kind != OCD_REWARD_TARGET_SPEED && !cand_weights) return OCD_ERR_INVALID_ARG;
+    const int C = d->n_cars, T = d->episode_len, D = OCD_N_FEATURES(d->reward_kind, d->n_lanes);
     (void)n_threads;
 #ifdef _OPENMP
     const int nt = n_threads > 0 ? n_threads : omp_get_max_threads();
@@ -671,7 +682,7 @@ int32_t ocd_reward_batch_cpu(const ocd_scenario_desc *d, const float *world_stat
                              float *feats_out, float *reward_out, int64_t B)
 {
     if (!check_desc(d) || !world_state) return OCD_ERR_INVALID_ARG;
-    const int C = d->n_cars, D = d->n_lanes + 4;
+    const int C = d->n_cars, D = OCD_N_FEATURES(d->reward_kind, d->n_lanes);
     for (int64_t b = 0; b < B; ++b) {
         const float r = ocd_oracle_reward(d, world_state + b * C * 4, weights,
                                           feats_out ? feats_out + b * D : NULL, NULL);

@@ -313,3 +313,58 @@ def test_generate_plan_from_a_foreign_state_uses_the_cars_own_speed(hip, oracle)
     assert same(planner.last_losses, ref["all_losses"][0])
     naive = oracle.plan_batch(d, np.stack(state)[None], car.weights.astype(np.float32))     # the state's own speed instead
     assert not same(naive["all_losses"][0][3:], ref["all_losses"][0][3:])
+
+
+# ---- the planning car of the reference's inverse-optimal-control tests -----------------------------
+@pytest.mark.parametrize("friction,n_iter,traj_len", [(0.0, 10, 6), (0.2, 200, 5)])
+def test_linear_target_speed_planner_car(hip, oracle, friction, n_iter, traj_len):
+    """reward_design/tests/test_first_order_ioc.py:29-79: a LinearTargetSpeedPlannerCar (features [v, (v - target)^2],
+    weights (2, -1), target 0, lr 5.0) is stepped through world.step() to make the demonstration trajectory.
+    friction 0: "this leads to zero controls" -- exactly; friction 0.2: bit for bit the oracle's episode."""
+    from l4dc_mpc_ocd_amd.interact_drive.reward_design.tests.linearTargetSpeedPlannerCar import LinearTargetSpeedPlannerCar
+    from l4dc_mpc_ocd_amd.interact_drive.world import CarWorld
+    world = CarWorld()
+    car = LinearTargetSpeedPlannerCar(world, np.array([0., 0., 1., PI_2], dtype=np.float32), horizon=5, target_speed=0.,
+                                      weights=np.array([2., -1.], dtype=np.float32), friction=friction,
+                                      planner_args=dict(n_iter=n_iter, learning_rate=5.0))
+    world.add_car(car)
+    assert same(car.weights, np.array([2., -1.], dtype=np.float32) / np.linalg.norm(np.array([2., -1.], dtype=np.float32)))
+    assert same(car.features(world.state, None), [1.0, 1.0])
+    scn = scenarios.linear_target_speed(horizon=5, n_iter=n_iter, learning_rate=5.0, friction=friction, episode_len=traj_len)
+    ref = oracle.rollout(scn.desc, np.array([[0., 0., 1., PI_2]]), car.weights[None].astype(np.float32), want_traj=True)
+    trajectory = []
+    for t in range(traj_len):
+        past_state, controls, next_state = world.step()
+        trajectory.append((past_state, controls))
+        assert same(controls[0], ref["ctrl"][0][t]) and same(next_state[0], ref["traj"][0][t + 1, 0])
+    if friction == 0.0:
+        assert all(same(c[0], [0.0, 0.0]) for _, c in trajectory)               # "this leads to zero controls"
+    else:
+        assert any(abs(float(np.asarray(c[0])[0])) > 1e-3 for _, c in trajectory)   # with drag the car has to accelerate
+
+
+def test_linear_target_speed_batch_bitwise(hip, oracle):
+    from l4dc_mpc_ocd_amd.engine import Engine
+    scn = scenarios.linear_target_speed(horizon=7, n_iter=40, learning_rate=0.5, friction=0.2, target_speed=0.8, episode_len=9)
+    eng = Engine(scn, "cuda:0")
+    rng = np.random.default_rng(12)
+    B = 50
+    ws = np.stack([rng.uniform(-0.2, 0.2, B), rng.uniform(-1, 1, B), rng.uniform(0.1, 2.0, B), PI_2 + rng.uniform(-0.5, 0.5, B)], axis=1)
+    ws = ws.astype(np.float32)[:, None, :]
+    w = np.stack([scenarios.normalize_like_reference(rng.standard_normal(2)).astype(np.float32) for _ in range(B)])
+    got = eng.plan_batch(ws, w, want_all=True)
+    ref = oracle.plan_batch(scn.desc, ws, w)
+    assert same(got["all_plans"], ref["all_plans"]) and same(got["all_losses"], ref["all_losses"])
+    assert np.array_equal(got["best_init"], ref["best_init"])
+    feats, rew = eng.reward_batch(ws, w[0])
+    for b in range(B):
+        r, f, _ = oracle.reward(scn.desc, ws[b], w[0])
+        assert same(feats[b], f) and same(rew[b], r)
+    u = rng.uniform(-2, 2, (B, 7, 2)).astype(np.float32)
+    out = eng.mpc_reward_batch(ws, w, u)
+    for b in range(0, B, 7):
+        r, g, _ = oracle.mpc_reward(scn.desc, ws[b], w[b], u[b])
+        assert same(out["reward"][b], r) and same(out["grad"][b], g)
+    ro = eng.rollout(ws[:5, 0], w[:4], want_traj=True)
+    rr = oracle.rollout(scn.desc, ws[:5, 0], w[:4], want_traj=True)
+    assert same(ro["returns"], rr["returns"]) and same(ro["ctrl"], rr["ctrl"]) and same(ro["traj"], rr["traj"])

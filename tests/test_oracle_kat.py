@@ -5,6 +5,8 @@ Sources (reference tree):
   interact_drive/math_utils.py:19-26,65-71,140-147          doctests of _f, smooth_threshold, smooth_bump
   interact_drive/planner/tests/targetSpeedRewardMaximizerCar.py:17-27   reward doctest
   interact_drive/planner/tests/test_naivePlanner.py:21-32,50-63         planner KATs (atol 1e-5)
+  interact_drive/reward_design/tests/test_first_order_ioc.py:29-60, tests/linearTargetSpeedPlannerCar.py:36-44
+                                                             "this leads to zero controls" (linear target-speed car)
 """
 import numpy as np
 import pytest
@@ -95,3 +97,41 @@ def test_planner_with_other_controls_runs(oracle):
     other = np.zeros((1, 3, 2), dtype=np.float32)
     out = oracle.plan_batch(scn.desc, ws, scn.designer_weights, other_plans=other)
     assert np.all(np.isfinite(out["plans"]))
+
+
+def test_linear_target_speed_car_leads_to_zero_controls(oracle):
+    """test_first_order_ioc.py:29-49: LinearTargetSpeedPlannerCar, weights (2, -1), target_speed 0, v = 1, friction 0,
+    horizon 5, n_iter 10, lr 5.0 -- "this leads to zero controls": d/dv (w0 v + w1 v^2) = w0 + 2 w1 v vanishes at
+    v = 1 for w = (2, -1)/sqrt(5), exactly in fp32 (2 w1 == -w0 bit for bit), so SGD never moves the controls and
+    the six world steps of the test's trajectory all apply (0, 0)."""
+    scn = scenarios.linear_target_speed(horizon=5, n_iter=10, learning_rate=5.0, friction=0.0, target_speed=0.0)
+    w = scenarios.normalize_like_reference(np.array([2., -1.], dtype=np.float32)).astype(np.float32)   # LinearRewardCar.__init__
+    assert w[0] == -2 * w[1]
+    r, feats, _ = oracle.reward(scn.desc, [[0., 0., 1., PI_2]], w)
+    assert np.array_equal(feats, [1.0, 1.0]) and r == np.float32(np.float32(w[0] * 1.0) + np.float32(w[1] * 1.0))
+    out = oracle.plan_batch(scn.desc, [[0., 0., 1., PI_2]], w)
+    assert np.array_equal(out["plans"][0], np.zeros((5, 2), dtype=np.float32))          # exactly zero controls
+    assert out["best_init"][0] == 0 and out["all_losses"][0, 0] == out["all_losses"][0, 1] == out["all_losses"][0, 2]
+    assert np.array_equal(out["all_plans"][0, 2, :, 1], np.full(5, 0.65, dtype=np.float32))   # heading never enters
+    ro = oracle.rollout(scn.desc, np.array([[0., 0., 1., PI_2]]), w[None], want_traj=True)
+    assert np.array_equal(ro["ctrl"][0], np.zeros((6, 2), dtype=np.float32))
+    assert np.array_equal(ro["traj"][0][:, 0, 2], np.ones(7, dtype=np.float32))          # the speed stays 1
+    np.testing.assert_allclose(ro["traj"][0][:, 0, 1], 0.1 * np.arange(7), rtol=1e-6)    # y advances by v dt
+
+
+def test_linear_target_speed_gradient_matches_torch(oracle):
+    """The same car with friction (test_first_order_ioc.py:62-79: friction 0.2, n_iter 200): objective and gradient
+    against torch autograd on the reference's feature expressions."""
+    import torch_restatement as tr
+    scn = scenarios.linear_target_speed(horizon=5, n_iter=200, learning_rate=5.0, friction=0.2, target_speed=0.0)
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        ws = np.array([[rng.uniform(-0.2, 0.2), rng.uniform(-1, 1), rng.uniform(0.2, 2.0), PI_2 + rng.uniform(-0.4, 0.4)]], dtype=np.float32)
+        w = scenarios.normalize_like_reference(rng.standard_normal(2)).astype(np.float32)
+        u = np.stack([rng.uniform(-2, 2, 5), rng.uniform(-1, 1, 5)], axis=1).astype(np.float32)
+        r, g, traj = oracle.mpc_reward(scn.desc, ws, w, u)
+        r64, g64, t64 = tr.mpc_reward_and_grad(scn.desc, ws, w, u)
+        np.testing.assert_allclose(traj, t64, rtol=1e-5, atol=1e-6)
+        assert abs(r - r64) <= 2e-5 * max(1.0, abs(r64))
+        assert np.abs(g - g64).max() <= 2e-5 * max(1e-3, np.abs(g64).max())
+        assert np.all(g[:, 1] == 0.0)                      # the heading rate never enters the reward

@@ -92,6 +92,9 @@ class World:
     def reward_fn(self, state, weights):
         if self.d.reward_kind == 1:
             return -(state[0][2] - self.target_speed) ** 2
+        if self.d.reward_kind == 2:                    # linearTargetSpeedPlannerCar.py:36-44
+            velocity = state[0][2]
+            return torch.sum(weights * torch.stack([velocity, (velocity - self.target_speed) ** 2]))
         return torch.sum(weights * self.features(state))
 
     def mpc_reward(self, init_state, controls, weights, other_controls=None):
