@@ -283,46 +283,39 @@ mpc_chunk_kernel(const KernelParams p)
             Q4 q[S];
             float rw[S];
             if constexpr (lane_feats && LAT) {
-                // the masks of all S steps first (their ballots settle while the evaluations issue); per step one test
-                // chooses between one feature per lane and the rarer multi-feature evaluations; no "none active" path
-                float xn_[S], yn_[S];
-                bool nf_[S], nc_[S][NOA];
-                unsigned long long mf_[S], mc_[S];         // fence + car lanes, two-car lanes
-                {
-                    float x = xs, y = ys;
-#pragma unroll
-                    for (int s = 0; s < S; ++s) {
-                        x = x + cd[s];
-                        y = y + sd[s];
-                        xn_[s] = x; yn_[s] = y;
-                        nf_[s] = needs_fence(d, x);
-                        const unsigned long long mf = __builtin_amdgcn_ballot_w64(nf_[s]) & live_mask;
-                        unsigned long long mc_any = 0ull;
-                        mf_[s] = 0ull; mc_[s] = 0ull;
-                        nc_[s][0] = false;
-#pragma unroll
-                        for (int j = 0; j < NO; ++j) {
-                            const float dx = x - bg[s][j].cx, dy = y - bg[s][j].cy;
-                            const bool ncx = __builtin_fabsf(dx) < wx1[s][j], ncy = __builtin_fabsf(dy) < wy1[s][j];
-                            nc_[s][j] = ncx && ncy;
-                            const unsigned long long mj = __builtin_amdgcn_ballot_w64(ncx) & __builtin_amdgcn_ballot_w64(ncy) & live_mask;
-                            mf_[s] |= (mj & mf);
-                            mc_[s] |= (mj & mc_any);
-                            mc_any |= mj;
-                        }
-                    }
-                }
-                OCD_STAMP(4);                              // choice of the evaluation
+                // per step ONE test chooses between one feature per lane (straight line, no sub-skips) and the rarer
+                // multi-feature evaluations; no "none active" path.  (Hoisting the masks of all S steps in front of
+                // the evaluations hides the ballot latency but keeps 5 x (1 + NO) lane masks alive: SGPR spills.)
+                float x = xs, y = ys;
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
-                    if (__builtin_expect((mf_[s] | mc_[s]) != 0ull, 0)) {
-                        if (mc_[s] != 0ull)
-                            rw[s] = reward_state<NO, L, GRAD>(d, w, xn_[s], yn_[s], vn[s], sn[s], cn[s], bg[s], q[s], nullptr, true, true);
+                    x = x + cd[s];
+                    y = y + sd[s];
+                    const float xn = x, yn = y;
+                    bool nc[NOA];
+                    nc[0] = false;
+                    const bool nf = needs_fence(d, xn);
+                    const unsigned long long mf = __builtin_amdgcn_ballot_w64(nf) & live_mask;
+                    unsigned long long mc_any = 0ull, multi_f = 0ull, multi_c = 0ull;
+#pragma unroll
+                    for (int j = 0; j < NO; ++j) {
+                        const float dx = xn - bg[s][j].cx, dy = yn - bg[s][j].cy;
+                        const bool ncx = __builtin_fabsf(dx) < wx1[s][j], ncy = __builtin_fabsf(dy) < wy1[s][j];
+                        nc[j] = ncx && ncy;
+                        const unsigned long long mj = __builtin_amdgcn_ballot_w64(ncx) & __builtin_amdgcn_ballot_w64(ncy) & live_mask;
+                        multi_f |= (mj & mf);
+                        multi_c |= (mj & mc_any);
+                        mc_any |= mj;
+                    }
+                    OCD_STAMP(4);                          // choice of the evaluation
+                    if (__builtin_expect((multi_f | multi_c) != 0ull, 0)) {
+                        if (multi_c != 0ull)
+                            rw[s] = reward_state<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], q[s], nullptr, true, true);
                         else
-                            rw[s] = reward_fc<NO, L, GRAD>(d, w, xn_[s], yn_[s], vn[s], sn[s], cn[s], bg[s], nc_[s], q[s], pkc);
+                            rw[s] = reward_fc<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], nc, q[s], pkc);
                         OCD_STAMP(5); OCD_STAMP_COUNT(12);
                     } else {
-                        rw[s] = reward_one<NO, L, GRAD, false>(d, w, xn_[s], yn_[s], vn[s], sn[s], cn[s], bg[s], nc_[s], nf_[s], true, true,
+                        rw[s] = reward_one<NO, L, GRAD, false>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], nc, nf, true, true,
                                                                q[s], pkc, lgc, live_mask);
                         OCD_STAMP(6); OCD_STAMP_COUNT(13);
                     }

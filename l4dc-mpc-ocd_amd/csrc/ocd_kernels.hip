@@ -456,10 +456,22 @@ mpc_kernel(const KernelParams p)
                 const bool has_f = mf != 0ull, has_col = mc_any != 0ull;
                 const unsigned long long any_feat = mf | mc_any;
                 OCD_STAMP(4);                              // choice of the evaluation
-                if constexpr (LAT) {
-                    // one feature per lane, straight line; the pass with a multi-feature lane is repaired afterwards,
-                    // out of line (the shapes that run LAT builds -- one wavefront per SIMD at H <= 16 -- are the
-                    // scenarios whose fence region and collision boxes do not overlap: it is rare or impossible there)
+                if constexpr (LAT && NO >= 2) {
+                    // several scripted cars: the reference's scenarios of that kind (replanning, merging) put cars where
+                    // their collision box overlaps the fence region, a pass with a multi-feature lane is COMMON (most
+                    // passes of the slowest wavefronts): decided before the evaluation, one evaluation per pass
+                    if (__builtin_expect((multi_f | multi_c) != 0ull, 0)) {
+                        if (multi_c != 0ull) r = reward_state<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, true, true);
+                        else r = reward_fc<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, nc, q, pkc);
+                        OCD_STAMP(5); OCD_STAMP_COUNT(12); // every feature / fence + one car per lane
+                    } else {
+                        r = reward_one<NO, L, GRAD, false, phi0_in_chain>(d, w, xn, yn, vn, sn, cn, bg, nc, nf, true, true, q, pkc, lgc, feat_mask);
+                        OCD_STAMP(6); OCD_STAMP_COUNT(13); // one feature per lane
+                    }
+                } else if constexpr (LAT) {
+                    // one scripted car (finite_horizon, local_opt: its collision box and the fence region do not overlap,
+                    // a multi-feature lane is rare or impossible): one feature per lane, straight line; the rare pass is
+                    // repaired afterwards, out of line -- the hot path carries no trace of it
                     r = reward_one<NO, L, GRAD, false, phi0_in_chain>(d, w, xn, yn, vn, sn, cn, bg, nc, nf, true, true, q, pkc, lgc, feat_mask);
                     OCD_STAMP(6); OCD_STAMP_COUNT(13);     // one feature per lane
                     if (__builtin_expect((multi_f | multi_c) != 0ull, 0)) {
@@ -948,7 +960,7 @@ static hipError_t launch_mpc(const KernelParams &p_in, hipStream_t st)
         else if (seg_cap && waves_seg <= simds) variant = V_SEG;
         else if (chunk_wins) variant = V_CHUNK;
         else if (seg_cap && waves_seg * 20 <= waves_lds * 21 && waves_seg <= 4 * simds) variant = V_SEG;
-        else if (row_cap && ceil_div(n, row_cap) * K <= simds) variant = V_ROW;
+        else if (row_cap && ceil_div(n, row_cap) * K <= simds + simds / 2) variant = V_ROW;   // (2 % ahead of V_LDS at 1.5 per SIMD)
     }
     if (variant == V_CHUNK) return launch_chunk_dispatch(H, NO, L, p, st, true, p.chunk_size, &chunk);
     int segs;
