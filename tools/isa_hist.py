@@ -113,13 +113,24 @@ def main():
 
         def cost(cls, form, shape):
             return rows[(cls, form)][shape]["ns_per_op_per_simd"]
-        rep = {"fast": ("v_mul_f32", "D"), "slow": ("v_cndmask_b32 (SGPR pair)", "D"), "cnd_vcc": ("v_cndmask_b32 (VCC)", "I"),
-               "trans": ("v_rcp_f32", "D"), "nop": ("s_nop 0", "D"), "bperm": ("ds_bpermute_b32", "I")}
-        print("  SIMD time of this range by the measured per-class costs (ns; salu / branch / wait / vmem priced as s_nop):")
-        dflt = ("s_nop 0", "D")
-        for shape in ("chip_1", "chip_2", "chip_4", "chip_8"):
-            parts = {k: v * cost(*rep.get(k, dflt), shape) for k, v in hist.items()}
-            print(f"    {shape}: {sum(parts.values()):8.1f} ns per wavefront-pass per SIMD slot  ("
+
+        def class_cost(k, shape):
+            if shape == "lone":
+                # a wavefront alone on its SIMD: 4.44 cycles per instruction of any class (v_rcp_f32: 8.44) at ~2.3 GHz
+                return rows[("v_rcp_f32", "D")]["cu_1wave"]["wave_cycles_per_op"] / 2.3 if k == "trans" else 4.44 / 2.3
+            if k == "cnd_vcc":
+                # IN SITU (a select between other instructions): from the V_SEG position chain, 2 v_add_f32 + 2 selects per
+                # round.  Back to back, VCC selects cost 9.6 ns each (row "v_cndmask_b32 (VCC)"): the kernels never do that.
+                return (cost("seg_fwd_xy<10>, per round", "D", shape) - 2 * cost("v_add_f32", "D", shape)) / 2
+            rep = {"fast": ("v_mul_f32", "D"), "slow": ("v_cndmask_b32 (SGPR pair)", "D"), "trans": ("v_rcp_f32", "D"),
+                   "bperm": ("ds_bpermute_b32", "I")}
+            return cost(*rep.get(k, ("s_nop 0", "D")), shape)
+
+        print("  SIMD time of this range by the measured per-class costs (ns; salu / branch / wait / vmem priced as s_nop;")
+        print("  'lone' = one wavefront per SIMD, issue-bound; chip_N = N wavefronts per SIMD, the SIMD's own time per wavefront):")
+        for shape in ("lone", "chip_2", "chip_4", "chip_8"):
+            parts = {k: v * class_cost(k, shape) for k, v in hist.items()}
+            print(f"    {shape:6s}: {sum(parts.values()):8.1f} ns  ("
                   + ", ".join(f"{k} {parts[k]:.0f}" for k, _ in hist.most_common()) + ")")
 
 if __name__ == "__main__":
