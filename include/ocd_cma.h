@@ -1,0 +1,55 @@
+/*
+ * ocd_cma.h -- host side of a CMA-ES generation around the episode kernel, in native code (libocd_cma.so, plain C,
+ * no HIP): ask, tell and the float64 fitness reduction.
+ *
+ * Replaces (reference file:line, relative to the reference tree)
+ *   cma.evolution_strategy.fmin2(self.eval_weights, ...)    interact_drive/reward_design/mpc_ord.py:33-45
+ *       (pycma: an unpinned, un-vendored dependency, setup.py:6 -- the sampling sequence here is NOT pycma's;
+ *        optimisation traces are "parity unpinned")
+ *   the reduction of the episode returns to a cost       interact_drive/reward_design/mpc_ord.py:102,126-151
+ * The Python binding is l4dc-mpc-ocd_amd/interact_drive/reward_design/cmaes.py (NativeCMAES); MPC_ORD.optimize_cmaes
+ * drives it with whole generations per kernel launch.
+ *
+ * Conventions: host pointers, caller-owned buffers, 0 = OK / -1 = invalid argument, no global state; one handle is
+ * not thread-safe, different handles are independent.
+ */
+#ifndef OCD_CMA_H
+#define OCD_CMA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OCD_CMA_MAX_DIM 64
+
+typedef struct ocd_cma ocd_cma;
+
+/* (mu/mu_w, lambda)-CMA-ES with Hansen's default strategy parameters, started at x0 [n] with step size sigma0;
+ * popsize 0 = 4 + floor(3 ln n) (pycma's default: 9 for the 7 weights of ThreeLaneTestCar); the normal deviates are
+ * numpy.random.RandomState(seed).standard_normal's stream, bit for bit. */
+int32_t ocd_cma_create(int32_t n, const double *x0, double sigma0, int32_t popsize, uint32_t seed, ocd_cma **out);
+void ocd_cma_destroy(ocd_cma *es);
+int32_t ocd_cma_popsize(const ocd_cma *es);
+
+/* Draw the normal deviates of the next population ahead of time (they do not depend on the state of the search):
+ * for callers with something to wait for -- the running episode kernel.  Optional; the stream is the same. */
+int32_t ocd_cma_prepare(ocd_cma *es);
+/* X [lambda, n] <- the next population: mean + sigma * C^(1/2) z (symmetric square root). */
+int32_t ocd_cma_ask(ocd_cma *es, double *X);
+/* The update of one generation from the population last asked for and its costs fitness [lambda] (lower is better). */
+int32_t ocd_cma_tell(ocd_cma *es, const double *X, const double *fitness);
+/* Any of the outputs may be NULL: mean [n], sigma, C [n, n], best_x [n], best_f, generations, evaluations,
+ * max_axis = the largest sqrt-eigenvalue of C (the stopping rule sigma * max_axis < tolx). */
+int32_t ocd_cma_state(const ocd_cma *es, double *mean, double *sigma, double *C, double *best_x, double *best_f,
+                      int64_t *gen, int64_t *counteval, double *max_axis);
+
+/* returns [P, N, S] fp32 sample rewards -> cost_out [P]: samples summed sequentially in fp32 (TensorFlow scalars,
+ * mpc_ord.py:102), inits sequentially in float64 (mpc_ord.py:126,137), / S, negated (mpc_ord.py:139,151). */
+int32_t ocd_fitness_from_returns(const float *returns, int64_t P, int64_t N, int64_t S, double *cost_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

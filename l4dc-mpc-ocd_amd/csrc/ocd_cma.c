@@ -1,0 +1,343 @@
+/* ocd_cma.c -- host side of a CMA-ES generation in native code: ask, tell and the float64 fitness reduction.
+ *
+ * What it replaces (reference file:line): the reference hands MPC_ORD.eval_weights to pycma's
+ * cma.evolution_strategy.fmin2 (interact_drive/reward_design/mpc_ord.py:33-45; pycma is an unpinned, un-vendored
+ * dependency, setup.py:6) and reduces the episode returns in Python (mpc_ord.py:126-151).  Around a 1.6 ms
+ * episode kernel the numpy version of these steps costs ~70 us of call overhead per generation for ~2 us of
+ * arithmetic (7 weights, 64 candidates); here they are three C calls.
+ *
+ * Algorithm: the textbook (mu/mu_w, lambda)-CMA-ES with default strategy parameters (N. Hansen, "The CMA Evolution
+ * Strategy: A Tutorial", 2016), the same formulas as interact_drive/reward_design/cmaes.py (the numpy twin the
+ * tests compare it with).  Candidates are m + sigma * C^(1/2) z with the SYMMETRIC square root, so the sample path
+ * does not depend on the order or sign of the eigenvectors (numpy's LAPACK and the Jacobi sweep below give the same
+ * candidates to rounding).  z comes from MT19937 + the polar method exactly as numpy.random.RandomState(seed)
+ * .standard_normal does (bit-identical stream; tests/test_host_mirror.py).  The sampling sequence is not pycma's:
+ * optimisation traces are "parity unpinned" (SURVEY.md 8c); the fitness values are bit-exact.
+ *
+ * Plain C11, no HIP: libocd_cma.so.  Declared in include/ocd_cma.h. */
+#include "../../include/ocd_cma.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MT_N 624
+#define MT_M 397
+
+struct ocd_cma {
+    int n, lam, mu;
+    double sigma, mueff, cc, cs, c1, cmu, damps, chiN;
+    double *mean, *weights, *pc, *ps, *C, *B, *D, *sqrtC, *invsqrtC, *y, *best_x, *tmp, *work;
+    double best_f, max_d;
+    int64_t gen, counteval;
+    int *order;
+    double *z;                /* [lam, n] the normal deviates of the NEXT population, drawn ahead by ocd_cma_prepare */
+    int z_ready;
+    /* numpy.random.RandomState(seed): MT19937 + cached second value of the polar method */
+    uint32_t mt[MT_N];
+    int mti, has_gauss;
+    double gauss;
+};
+
+/* ---- MT19937 as numpy's legacy RandomState seeds and draws it ---- */
+static void mt_seed(ocd_cma *es, uint32_t seed)
+{
+    for (int pos = 0; pos < MT_N; ++pos) {
+        es->mt[pos] = seed;
+        seed = 1812433253u * (seed ^ (seed >> 30)) + (uint32_t)pos + 1u;
+    }
+    es->mti = MT_N;
+    es->has_gauss = 0;
+    es->gauss = 0.0;
+}
+
+static uint32_t mt_next(ocd_cma *es)
+{
+    if (es->mti >= MT_N) {
+        uint32_t *mt = es->mt, y;
+        int kk;
+        for (kk = 0; kk < MT_N - MT_M; ++kk) {
+            y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
+            mt[kk] = mt[kk + MT_M] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        for (; kk < MT_N - 1; ++kk) {
+            y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
+            mt[kk] = mt[kk + (MT_M - MT_N)] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        y = (mt[MT_N - 1] & 0x80000000u) | (mt[0] & 0x7fffffffu);
+        mt[MT_N - 1] = mt[MT_M - 1] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        es->mti = 0;
+    }
+    uint32_t y = es->mt[es->mti++];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+static double mt_double(ocd_cma *es)
+{
+    const int32_t a = (int32_t)(mt_next(es) >> 5), b = (int32_t)(mt_next(es) >> 6);
+    return (a * 67108864.0 + b) / 9007199254740992.0;
+}
+
+static double gauss(ocd_cma *es)          /* numpy's legacy_gauss */
+{
+    if (es->has_gauss) {
+        const double t = es->gauss;
+        es->has_gauss = 0;
+        es->gauss = 0.0;
+        return t;
+    }
+    double f, x1, x2, r2;
+    do {
+        x1 = 2.0 * mt_double(es) - 1.0;
+        x2 = 2.0 * mt_double(es) - 1.0;
+        r2 = x1 * x1 + x2 * x2;
+    } while (r2 >= 1.0 || r2 == 0.0);
+    f = sqrt(-2.0 * log(r2) / r2);
+    es->gauss = f * x1;
+    es->has_gauss = 1;
+    return f * x2;
+}
+
+/* ---- symmetric eigendecomposition, cyclic Jacobi: A (n x n, symmetric, destroyed) -> eigenvalues d, vectors V (columns) ---- */
+static void jacobi_eigh(int n, double *A, double *d, double *V)
+{
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int i = 0; i < n; ++i) {
+            diag += A[i * n + i] * A[i * n + i];
+            for (int j = i + 1; j < n; ++j) off += A[i * n + j] * A[i * n + j];
+        }
+        if (off <= 1e-60 + 1e-34 * diag) break;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = A[p * n + q];
+                if (apq == 0.0) continue;
+                const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; ++k) {              /* A <- A J */
+                    const double akp = A[k * n + p], akq = A[k * n + q];
+                    A[k * n + p] = c * akp - s * akq;
+                    A[k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; ++k) {              /* A <- J^T A */
+                    const double apk = A[p * n + k], aqk = A[q * n + k];
+                    A[p * n + k] = c * apk - s * aqk;
+                    A[q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double vkp = V[k * n + p], vkq = V[k * n + q];
+                    V[k * n + p] = c * vkp - s * vkq;
+                    V[k * n + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    for (int i = 0; i < n; ++i) d[i] = A[i * n + i];
+}
+
+/* sqrtC = B diag(D) B^T, invsqrtC = B diag(1/D) B^T from C (D = sqrt(max(eigenvalue, 1e-20))) */
+static void decompose(ocd_cma *es)
+{
+    const int n = es->n;
+    memcpy(es->work, es->C, sizeof(double) * n * n);
+    jacobi_eigh(n, es->work, es->D, es->B);
+    es->max_d = 0.0;
+    for (int i = 0; i < n; ++i) {
+        es->D[i] = sqrt(es->D[i] > 1e-20 ? es->D[i] : 1e-20);
+        if (es->D[i] > es->max_d) es->max_d = es->D[i];
+    }
+    for (int i = 0; i < n; ++i)
+        for (int j = i; j < n; ++j) {
+            double a = 0.0, b = 0.0;
+            for (int k = 0; k < n; ++k) {
+                const double bb = es->B[i * n + k] * es->B[j * n + k];
+                a += bb * es->D[k];
+                b += bb / es->D[k];
+            }
+            es->sqrtC[i * n + j] = es->sqrtC[j * n + i] = a;
+            es->invsqrtC[i * n + j] = es->invsqrtC[j * n + i] = b;
+        }
+}
+
+int32_t ocd_cma_create(int32_t n, const double *x0, double sigma0, int32_t popsize, uint32_t seed, ocd_cma **out)
+{
+    if (!out) return -1;
+    *out = NULL;
+    if (n < 1 || n > OCD_CMA_MAX_DIM || !x0 || !(sigma0 > 0.0) || popsize < 0) return -1;
+    ocd_cma *es = (ocd_cma *)calloc(1, sizeof(ocd_cma));
+    if (!es) return -1;
+    es->n = n;
+    es->lam = popsize > 0 ? popsize : 4 + (int)(3.0 * log((double)n));
+    if (es->lam < 2) { free(es); return -1; }
+    es->mu = es->lam / 2;
+    const size_t nn = (size_t)n * n;
+    const size_t total = (size_t)n * 6 + (size_t)es->mu + nn * 6 + (size_t)es->lam * n * 2;
+    double *mem = (double *)calloc(total, sizeof(double));
+    es->order = (int *)calloc((size_t)es->lam, sizeof(int));
+    if (!mem || !es->order) { free(mem); free(es->order); free(es); return -1; }
+    double *p = mem;
+    es->mean = p; p += n; es->pc = p; p += n; es->ps = p; p += n; es->D = p; p += n; es->best_x = p; p += n; es->tmp = p; p += n;
+    es->weights = p; p += es->mu;
+    es->C = p; p += nn; es->B = p; p += nn; es->sqrtC = p; p += nn; es->invsqrtC = p; p += nn; es->work = p; p += 2 * nn;
+    es->y = p; p += (size_t)es->lam * n;
+    es->z = p;
+    memcpy(es->mean, x0, sizeof(double) * n);
+    es->sigma = sigma0;
+    double wsum = 0.0, w2 = 0.0;
+    for (int i = 0; i < es->mu; ++i) { es->weights[i] = log(es->mu + 0.5) - log((double)(i + 1)); wsum += es->weights[i]; }
+    for (int i = 0; i < es->mu; ++i) { es->weights[i] /= wsum; w2 += es->weights[i] * es->weights[i]; }
+    es->mueff = 1.0 / w2;
+    const double me = es->mueff, dn = (double)n;
+    es->cc = (4 + me / dn) / (dn + 4 + 2 * me / dn);
+    es->cs = (me + 2) / (dn + me + 5);
+    es->c1 = 2 / ((dn + 1.3) * (dn + 1.3) + me);
+    es->cmu = 2 * (me - 2 + 1 / me) / ((dn + 2) * (dn + 2) + me);
+    if (es->cmu > 1 - es->c1) es->cmu = 1 - es->c1;
+    const double dm = sqrt((me - 1) / (dn + 1)) - 1;
+    es->damps = 1 + 2 * (dm > 0.0 ? dm : 0.0) + es->cs;
+    es->chiN = sqrt(dn) * (1 - 1 / (4 * dn) + 1 / (21 * dn * dn));
+    for (int i = 0; i < n; ++i) {
+        es->C[i * n + i] = es->B[i * n + i] = es->sqrtC[i * n + i] = es->invsqrtC[i * n + i] = 1.0;
+        es->D[i] = 1.0;
+    }
+    es->max_d = 1.0;
+    es->best_f = INFINITY;
+    mt_seed(es, seed);
+    *out = es;
+    return 0;
+}
+
+void ocd_cma_destroy(ocd_cma *es)
+{
+    if (!es) return;
+    free(es->mean);           /* the one block all double arrays live in */
+    free(es->order);
+    free(es);
+}
+
+int32_t ocd_cma_popsize(const ocd_cma *es) { return es ? es->lam : -1; }
+
+/* The deviates do not depend on the state of the search: a caller with something to wait for (the running episode
+ * kernel) draws the next population's while it waits; ask() draws them itself otherwise.  Same stream either way. */
+int32_t ocd_cma_prepare(ocd_cma *es)
+{
+    if (!es) return -1;
+    if (!es->z_ready) {
+        const size_t m = (size_t)es->lam * es->n;
+        for (size_t i = 0; i < m; ++i) es->z[i] = gauss(es);
+        es->z_ready = 1;
+    }
+    return 0;
+}
+
+int32_t ocd_cma_ask(ocd_cma *es, double *X)
+{
+    if (!es || !X) return -1;
+    const int n = es->n, lam = es->lam;
+    ocd_cma_prepare(es);
+    es->z_ready = 0;
+    for (int k = 0; k < lam; ++k) {
+        const double *z = es->z + (size_t)k * n;
+        double *y = es->y + (size_t)k * n;
+        for (int i = 0; i < n; ++i) {               /* y = C^(1/2) z (symmetric root) */
+            double a = 0.0;
+            for (int j = 0; j < n; ++j) a += es->sqrtC[i * n + j] * z[j];
+            y[i] = a;
+            X[(size_t)k * n + i] = es->mean[i] + es->sigma * a;
+        }
+    }
+    return 0;
+}
+
+int32_t ocd_cma_tell(ocd_cma *es, const double *X, const double *fitness)
+{
+    if (!es || !X || !fitness) return -1;
+    const int n = es->n, lam = es->lam, mu = es->mu;
+    /* stable argsort of the fitness (insertion sort: lam is small) */
+    for (int k = 0; k < lam; ++k) {
+        int j = k;
+        while (j > 0 && fitness[es->order[j - 1]] > fitness[k]) { es->order[j] = es->order[j - 1]; --j; }
+        es->order[j] = k;
+    }
+    const int b = es->order[0];
+    if (fitness[b] < es->best_f) {
+        es->best_f = fitness[b];
+        memcpy(es->best_x, X + (size_t)b * n, sizeof(double) * n);
+    }
+    es->counteval += lam;
+    double *yw = es->tmp;
+    for (int i = 0; i < n; ++i) yw[i] = 0.0;
+    for (int k = 0; k < mu; ++k) {
+        const double *y = es->y + (size_t)es->order[k] * n;
+        for (int i = 0; i < n; ++i) yw[i] += es->weights[k] * y[i];
+    }
+    for (int i = 0; i < n; ++i) es->mean[i] += es->sigma * yw[i];
+    const double cps = sqrt(es->cs * (2 - es->cs) * es->mueff);
+    double ps2 = 0.0;
+    for (int i = 0; i < n; ++i) {
+        double a = 0.0;
+        for (int j = 0; j < n; ++j) a += es->invsqrtC[i * n + j] * yw[j];
+        es->ps[i] = (1 - es->cs) * es->ps[i] + cps * a;
+        ps2 += es->ps[i] * es->ps[i];
+    }
+    const double ps_norm = sqrt(ps2);
+    const int hsig = ps_norm / sqrt(1 - pow(1 - es->cs, 2.0 * (double)es->counteval / lam)) / es->chiN < 1.4 + 2.0 / (n + 1);
+    const double cpc = hsig ? sqrt(es->cc * (2 - es->cc) * es->mueff) : 0.0;
+    for (int i = 0; i < n; ++i) es->pc[i] = (1 - es->cc) * es->pc[i] + cpc * yw[i];
+    const double keep = (1 - es->c1 - es->cmu) + es->c1 * (hsig ? 0.0 : es->cc * (2 - es->cc));
+    for (int i = 0; i < n; ++i)
+        for (int j = i; j < n; ++j) {
+            double rank_mu = 0.0;
+            for (int k = 0; k < mu; ++k) {
+                const double *y = es->y + (size_t)es->order[k] * n;
+                rank_mu += es->weights[k] * y[i] * y[j];
+            }
+            const double c = keep * es->C[i * n + j] + es->c1 * es->pc[i] * es->pc[j] + es->cmu * rank_mu;
+            es->C[i * n + j] = es->C[j * n + i] = c;        /* symmetric by construction */
+        }
+    es->sigma *= exp((es->cs / es->damps) * (ps_norm / es->chiN - 1));
+    decompose(es);
+    es->gen += 1;
+    return 0;
+}
+
+int32_t ocd_cma_state(const ocd_cma *es, double *mean, double *sigma, double *C, double *best_x, double *best_f,
+                      int64_t *gen, int64_t *counteval, double *max_axis)
+{
+    if (!es) return -1;
+    const int n = es->n;
+    if (mean) memcpy(mean, es->mean, sizeof(double) * n);
+    if (sigma) *sigma = es->sigma;
+    if (C) memcpy(C, es->C, sizeof(double) * n * n);
+    if (best_x) memcpy(best_x, es->best_x, sizeof(double) * n);
+    if (best_f) *best_f = es->best_f;
+    if (gen) *gen = es->gen;
+    if (counteval) *counteval = es->counteval;
+    if (max_axis) *max_axis = es->max_d;
+    return 0;
+}
+
+/* [P*N*S] fp32 sample rewards -> [P] costs with the reference's accumulation types (mpc_ord.py:102,126-151): samples
+ * summed sequentially in fp32, inits sequentially in float64, / num_samples, negated. */
+int32_t ocd_fitness_from_returns(const float *returns, int64_t P, int64_t N, int64_t S, double *cost_out)
+{
+    if (!returns || !cost_out || P < 0 || N < 1 || S < 1) return -1;
+    for (int64_t p = 0; p < P; ++p) {
+        double total = 0.0;
+        for (int64_t i = 0; i < N; ++i) {
+            const float *r = returns + (p * N + i) * S;
+            float per_init = r[0];
+            for (int64_t s = 1; s < S; ++s) per_init = per_init + r[s];
+            total = (i == 0) ? (double)per_init : total + (double)per_init;
+        }
+        total = total / (double)S;
+        cost_out[p] = -total;
+    }
+    return 0;
+}

@@ -10,7 +10,7 @@ import time
 
 import numpy as np
 
-from .cmaes import CMAES
+from .cmaes import CMAES, NativeCMAES, fitness_from_returns_native  # noqa: F401
 from .. import experiments  # noqa: F401
 from ..experiments._sampling import make_get_init_state
 from .._describe import describe, engine_for
@@ -128,9 +128,9 @@ class MPC_ORD:
         return t1
 
     def host_split_ms(self):
-        """Median milliseconds per generation of each host-side segment since optimize_cmaes started
-        (the first generation, which pays allocations, is dropped)."""
-        return {k: float(np.median(v[1:] if len(v) > 1 else v) * 1e3) for k, v in self.host_split.items()}
+        """Median milliseconds per generation of each host-side segment over the last 32 generations of the run (the
+        first ones pay allocations and run on a GPU whose clocks are still rising)."""
+        return {k: float(np.median(v[-32:]) * 1e3) for k, v in self.host_split.items()}
 
     def _returns(self, inits, weights_2d, while_running=None):
         """fp32 sample rewards [P, N, S] of every (candidate, init, sample) episode; sharded when distributed.
@@ -217,7 +217,7 @@ class MPC_ORD:
         t = time.perf_counter()
         self.last_returns = ret
         P, N, S = ret.shape
-        cost = sharding.fitness_from_returns(ret.reshape(-1), P, N, S)
+        cost = fitness_from_returns_native(ret.reshape(-1), P, N, S)    # == sharding.fitness_from_returns, one C call
         self._pending_history = (hist["Wn"], cost)
         if not self._defer_history:
             self._flush_history()
@@ -247,13 +247,13 @@ class MPC_ORD:
         assert not self.done
         self.should_save_history = True
         self.eval_weights(self.designer_weights)                       # "Iteration 0" baseline
-        es = CMAES(list(self.designer_weights), sigma0, popsize=popsize, seed=seed)
+        es = NativeCMAES(list(self.designer_weights), sigma0, popsize=popsize, seed=seed)   # csrc/ocd_cma.c
         self.generation_seconds = []
         self.fitness_seconds = []
         self.host_split = {}
         self._eng_fixed = self._engine()                           # world and car do not change inside the loop
         self._defer_history = self.save_path is None               # (a saved history must be complete at every dump)
-        self._overlap_hooks = [es.finish_tell]
+        self._overlap_hooks = [es.prepare]                          # the next population's deviates, while the GPU works
         while True:
             t0 = time.perf_counter()                               # a generation: ask, fitness of the population, tell
             X = es.ask()
