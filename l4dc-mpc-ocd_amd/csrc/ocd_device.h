@@ -717,42 +717,103 @@ struct LeafTable {
     const float *values;      // [n0, n1, n2]
     int32_t n[3];
     int32_t proj_kind;        // 0: (x, y, v)   1: (x, y, v * sin(heading))
+    float g0[3], scale[3];    // first boundary and (n - 1) / span per dimension: the corner search's starting guess
 };
 
-// last index i in [0, n-2] with grid[i] <= x (x is inside [grid[0], grid[n-1]])
-__device__ __forceinline__ int leaf_corner(const float *gr, int n, float x)
+// fill g0 / scale from the grid (once per kernel; any guess is corrected by the walk, so this is not part of the contract)
+__device__ __forceinline__ void leaf_guess_setup(LeafTable &lt)
 {
-    // start from the uniform-grid guess, then walk: exact for any ascending grid
-    const float span = gr[n - 1] - gr[0];
-    int c = (span > 0.0f) ? (int)(((x - gr[0]) / span) * (float)(n - 1)) : 0;
+    const float *g = lt.grid;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float span = g[lt.n[k] - 1] - g[0];
+        lt.g0[k] = g[0];
+        lt.scale[k] = (span > 0.0f) ? (float)(lt.n[k] - 1) / span : 0.0f;
+        g += lt.n[k];
+    }
+}
+
+// last index i in [0, n-2] with grid[i] <= x (x is inside [grid[0], grid[n-1]]), with that cell's lower / upper boundary.
+// Start from the uniform-grid guess c and read the FOUR boundaries around it in one go (independent loads: one LDS
+// latency instead of a dependent chain): the answer is c-1, c or c+1 for every uniform grid (np.linspace: the guess is
+// off by at most one).  `settled` reports whether the result satisfies the definition; the walk (leaf_corner_walk,
+// exact from any start, for arbitrary ascending grids) runs only for a wavefront with an unsettled lane.
+__device__ __forceinline__ int leaf_corner(const float *gr, int n, float x, float g0, float scale, bool &settled,
+                                           float &lower, float &upper)
+{
+    int c = (int)((x - g0) * scale);
     c = c < 0 ? 0 : (c > n - 2 ? n - 2 : c);
+    const float bm1 = gr[c > 0 ? c - 1 : 0], b0 = gr[c], b1 = gr[c + 1], b2 = gr[c + 2 < n ? c + 2 : n - 1];
+    const bool up = (c < n - 2) && (b1 <= x);
+    const bool down = !up && (c > 0) && (b0 > x);
+    const int cc = up ? c + 1 : (down ? c - 1 : c);
+    lower = up ? b1 : (down ? bm1 : b0);
+    upper = up ? b2 : (down ? b0 : b1);
+    settled = (cc == 0 || lower <= x) && (cc == n - 2 || x < upper);
+    return cc;
+}
+
+__device__ __forceinline__ int leaf_corner_walk(const float *gr, int n, float x, int c)
+{
     while (c < n - 2 && gr[c + 1] <= x) ++c;
     while (c > 0 && gr[c] > x) --c;
     return c;
 }
 
-// value and (GRAD) gradient w.r.t. the ego state of the terminal value at (x, y, v, heading)
-template <bool GRAD>
-__device__ __forceinline__ float leaf_value(const LeafTable &lt, float x, float y, float v, float sn, float cn, Q4 &q)
+// The lookup in two halves, so that a kernel can start the eight table loads (HBM / L2 latency) before the reward
+// features of the other lanes and consume them afterwards:
+//   leaf_prepare  coarse state, inside test, cell corner, steps, the eight corner values (loads issued)
+//   leaf_finish   value and (GRAD) gradient w.r.t. the ego state -- the arithmetic of the contract, in its order
+struct LeafLoad { float val[8], a[3], st[3]; bool inside; };
+
+__device__ __forceinline__ void leaf_prepare(const LeafTable &lt, float x, float y, float v, float sn, LeafLoad &ld)
 {
     const float xc[3] = {x, y, (lt.proj_kind == 1) ? (v * sn) : v};
     const float *gr[3] = {lt.grid, lt.grid + lt.n[0], lt.grid + lt.n[0] + lt.n[1]};
     bool inside = true;
 #pragma unroll
     for (int k = 0; k < 3; ++k) inside = inside && (xc[k] >= gr[k][0]) && (xc[k] <= gr[k][lt.n[k] - 1]);
+    ld.inside = inside;
+    int c[3];
+    float lo[3], hi[3];
+    bool settled = true;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        bool ok;
+        c[k] = leaf_corner(gr[k], lt.n[k], xc[k], lt.g0[k], lt.scale[k], ok, lo[k], hi[k]);   // (clamped outside the grid)
+        settled = settled && ok;
+    }
+    if (__builtin_expect(__ballot(inside && !settled) != 0ull, 0)) {            // a non-uniform grid: walk
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            c[k] = leaf_corner_walk(gr[k], lt.n[k], xc[k], c[k]);
+            lo[k] = gr[k][c[k]];
+            hi[k] = gr[k][c[k] + 1];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        ld.st[k] = hi[k] - lo[k];
+        ld.a[k] = xc[k] - lo[k];
+    }
+#pragma unroll
+    for (int i0 = 0; i0 < 2; ++i0)
+#pragma unroll
+        for (int i1 = 0; i1 < 2; ++i1)
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2)
+                ld.val[i0 * 4 + i1 * 2 + i2] = lt.values[((size_t)(c[0] + i0) * lt.n[1] + (c[1] + i1)) * lt.n[2] + (c[2] + i2)];
+}
+
+template <bool GRAD>
+__device__ __forceinline__ float leaf_finish(const LeafTable &lt, const LeafLoad &ld, float v, float sn, float cn, Q4 &q)
+{
     const float nanv = __int_as_float(0x7fc00000);
     // outside the grid the traced function returns the CONSTANT float('nan') (value_interpolation.py:59-60): the
     // value is NaN, its gradient w.r.t. the state is zero -- the other horizon steps keep their finite gradients
     if (GRAD) { q.qx = 0.0f; q.qy = 0.0f; q.qv = 0.0f; q.qth = 0.0f; }
-    if (!inside) return nanv;
-    int c[3];
-    float a[3], st[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        c[k] = leaf_corner(gr[k], lt.n[k], xc[k]);
-        st[k] = gr[k][c[k] + 1] - gr[k][c[k]];
-        a[k] = xc[k] - gr[k][c[k]];
-    }
+    if (!ld.inside) return nanv;
+    const float (&a)[3] = ld.a, (&st)[3] = ld.st;
     const float cell = (st[0] * st[1]) * st[2];
     // p[k][i]: (-1)**(i+1) * (x - g) + (1 - i) * step
     float p[3][2];
@@ -769,7 +830,7 @@ __device__ __forceinline__ float leaf_value(const LeafTable &lt, float x, float 
         for (int i1 = 0; i1 < 2; ++i1)
 #pragma unroll
             for (int i2 = 0; i2 < 2; ++i2) {
-                const float val = lt.values[((size_t)(c[0] + i0) * lt.n[1] + (c[1] + i1)) * lt.n[2] + (c[2] + i2)];
+                const float val = ld.val[i0 * 4 + i1 * 2 + i2];
                 const float pv01 = p[0][i0] * p[1][i1];
                 const float pv = pv01 * p[2][i2];
                 const float num = val * pv;
@@ -794,6 +855,15 @@ __device__ __forceinline__ float leaf_value(const LeafTable &lt, float x, float 
         else { q.qv = ga[2]; q.qth = 0.0f; }
     }
     return sum;
+}
+
+// value and (GRAD) gradient w.r.t. the ego state of the terminal value at (x, y, v, heading)
+template <bool GRAD>
+__device__ __forceinline__ float leaf_value(const LeafTable &lt, float x, float y, float v, float sn, float cn, Q4 &q)
+{
+    LeafLoad ld;
+    leaf_prepare(lt, x, y, v, sn, ld);
+    return leaf_finish<GRAD>(lt, ld, v, sn, cn, q);     // (callers fill lt.g0 / lt.scale with leaf_guess_setup)
 }
 
 } // namespace ocd

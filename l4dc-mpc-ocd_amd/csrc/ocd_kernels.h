@@ -26,6 +26,8 @@ struct LeafParams {
     const float *values;      // [n0, n1, n2]
     int32_t n[3];
     int32_t proj_kind;
+    int32_t grid_in_lds;      // 1: the launch reserved n0 + n1 + n2 floats of LDS behind the variant's own: the kernel stages
+                              //    the cell boundaries there (the corner search reads them 4-8 times per pass, dependently)
 };
 
 // Kernel argument block (passed by value: lives in the kernarg segment, read
@@ -94,6 +96,10 @@ struct KernelParams {
     X(10, 1, 3, 5) X(15, 1, 3, 5) X(15, 1, 3, 3) X(25, 1, 3, 5)                               \
     X(10, 2, 2, 5) X(15, 2, 2, 5) X(15, 2, 2, 3)                                              \
     X(10, 2, 3, 5) X(25, 2, 3, 5)
+
+// (H, NO, L) with V_ROW / V_SEG LAT builds that carry the terminal value: the reference's own horizons on the shape
+// its value grids are made for (coarse_value_iteration.py: the three-lane finite-horizon world)
+template <int HT, int NO, int L> struct leaf_specialised { static constexpr bool value = (HT == 5 || HT == 6) && NO == 1 && L == 3; };
 
 hipError_t launch_mpc_dispatch(int H, int NO, int L, const KernelParams &p, hipStream_t st, bool *supported);
 // V_CHUNK: *chunk = the chunk size it would use / used for this shape (0 = none): the compiled size that

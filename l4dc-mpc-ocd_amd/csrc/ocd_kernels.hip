@@ -86,7 +86,8 @@ __host__ __device__ constexpr Geo geo_lds(int H)
 }
 
 // ---------------------------------------------------------------- the kernel
-// LEAF: the terminal-value lookup (leaf_evaluation) is compiled into the generic kernel only.
+// LEAF: the terminal-value lookup (leaf_evaluation): the generic kernel for every shape, and the V_ROW / V_SEG LAT
+//   builds of the reference's own horizons (5, 6) on the finite_horizon / local_opt shape (OCD_LEAF_TABLE).
 // LAT (V_ROW / V_SEG): the launch puts at most one wavefront on a SIMD, so it lasts as long as its slowest
 //   wavefront, and a lone wavefront pays 2 issue slots for every branch it does not take, ~6 for one it
 //   takes (tools/microbench/valu_latency.hip).  The slowest wavefront has a fence or collision lane in
@@ -99,7 +100,6 @@ mpc_kernel(const KernelParams p)
 {
     static_assert(!LAT || V == V_ROW || V == V_SEG, "LAT is a V_ROW / V_SEG build");
     static_assert(HT > 0 || V == V_LDS, "the generic (run-time H) kernel exchanges through LDS");
-    static_assert(!LEAF || HT == 0, "the terminal value runs in the generic kernel");
     static_assert(V != V_ROW || HT <= 16, "V_ROW keeps a trajectory inside one 16-lane DPP row");
     constexpr int NOA = NO > 0 ? NO : 1;
     constexpr bool lane_feats = L > 0;
@@ -148,6 +148,22 @@ mpc_kernel(const KernelParams p)
             data2 = plane2 + (H - 1);                             // the segment's H terms, in order
         }
         sel = lds + ((V == V_LDS) ? (size_t)K * G.WAVE_FLOATS : 0);   // [2][K][ROWS][4] selection records
+    }
+    // LEAF: the cell boundaries of the value table (n0 + n1 + n2 floats) staged in LDS behind the variant's own use
+    LeafTable leaf;
+    leaf.grid = p.leaf.grid; leaf.values = p.leaf.values; leaf.proj_kind = p.leaf.proj_kind;
+    leaf.n[0] = p.leaf.n[0]; leaf.n[1] = p.leaf.n[1]; leaf.n[2] = p.leaf.n[2];
+    if constexpr (LEAF) {
+        if (p.leaf.grid_in_lds) {
+            const size_t off = (V == V_SEG) ? 0 : ((V == V_ROW) ? (size_t)2 * K * G.SEL_FLOATS
+                                                               : (size_t)K * G.WAVE_FLOATS + (size_t)2 * K * G.SEL_FLOATS);
+            float *lg = lds + off;
+            const int ng = p.leaf.n[0] + p.leaf.n[1] + p.leaf.n[2];
+            for (int i = threadIdx.x; i < ng; i += blockDim.x) lg[i] = p.leaf.grid[i];
+            __syncthreads();
+            leaf.grid = lg;
+        }
+        leaf_guess_setup(leaf);
     }
     // V_LDS, H-specialised: 0/1 masks of the forward speed recurrence: step i updates lane t iff i >= H-1-t
     float mfw[HT > 1 ? HT - 1 : 1];
@@ -214,9 +230,6 @@ mpc_kernel(const KernelParams p)
     const BumpGeom bg0 = {0.0f, 1.0f, 0.0f, 1.0f};
     const bool writer = live && kinit == 0 && first;          // one lane per trajectory writes its outputs
     constexpr bool has_leaf = LEAF;                           // terminal value replaces the last step's reward
-    LeafTable leaf;
-    leaf.grid = p.leaf.grid; leaf.values = p.leaf.values; leaf.proj_kind = p.leaf.proj_kind;
-    leaf.n[0] = p.leaf.n[0]; leaf.n[1] = p.leaf.n[1]; leaf.n[2] = p.leaf.n[2];
     // lanes whose reward features count (the last horizon step is scored by the terminal value instead)
     const bool feat_live = live && !(has_leaf && last);
     const unsigned long long feat_mask = __ballot(feat_live);
@@ -433,6 +446,11 @@ mpc_kernel(const KernelParams p)
             const float yn = y + sd;
             OCD_STAMP(3);                                  // position recurrence
 
+            // terminal value: corner search and the eight table loads start here, the features of the other lanes
+            // issue while they are in flight, leaf_finish consumes them afterwards
+            LeafLoad lload;
+            if constexpr (has_leaf) leaf_prepare(leaf, xn, yn, vn, sn, lload);
+
             // ===== reward features at the post-step state =====
             // wave-uniform choice of the evaluation: none of {fence, collisions} active on any live lane /
             // at most one of them per lane (reward_one) / everything (reward_state)
@@ -505,7 +523,7 @@ mpc_kernel(const KernelParams p)
             }
             if constexpr (has_leaf) {                      // naive_planner.py:69-70
                 Q4 ql;
-                const float rl_ = leaf_value<GRAD>(leaf, xn, yn, vn, sn, cn, ql);
+                const float rl_ = leaf_finish<GRAD>(leaf, lload, vn, sn, cn, ql);
                 r = last ? rl_ : r;
                 if (GRAD) {
                     q.qx = last ? ql.qx : q.qx; q.qy = last ? ql.qy : q.qy;
@@ -801,6 +819,7 @@ __global__ void objective_kernel(const KernelParams p, const float *controls, fl
     LeafTable leaf;
     leaf.grid = p.leaf.grid; leaf.values = p.leaf.values; leaf.proj_kind = p.leaf.proj_kind;
     leaf.n[0] = p.leaf.n[0]; leaf.n[1] = p.leaf.n[1]; leaf.n[2] = p.leaf.n[2];
+    if (has_leaf) leaf_guess_setup(leaf);
 
     // scripted cars as the planner models them
     float px[NOA], py[NOA], pv[NOA], pth[NOA];
@@ -942,9 +961,21 @@ static hipError_t launch_mpc(const KernelParams &p_in, hipStream_t st)
     int chunk = 0;                                                     // V_CHUNK: chunk size compiled for this shape
     (void)launch_chunk_dispatch(H, NO, L, p, st, false, p.chunk_size, &chunk);
     if (chunk && 64 / (K * (H / chunk)) < 1) chunk = 0;
+    // terminal value: the generic kernel (run-time H, V_LDS) for every shape; V_ROW / V_SEG LAT builds for the shapes of
+    // OCD_LEAF_TABLE while the batch is small enough for them (they are latency builds) and no diagnostics knob is set
+    constexpr bool leaf_fast = leaf_specialised<HT, NO, L>::value;
+    const bool leaf = p.leaf.values != nullptr;
+    const bool lat = L > 0 && NO > 0 && !p.no_skips && !p.no_unify && !p.no_latency_build;
+    const size_t leaf_lds = leaf ? (size_t)(p.leaf.n[0] + p.leaf.n[1] + p.leaf.n[2]) * sizeof(float) : 0;
+    if (leaf && !(leaf_fast && lat)) {
+        chunk = 0;                                                     // (the chunked kernel carries no terminal value)
+        p.scan_mode = 1;
+    } else if (leaf) {
+        chunk = 0;
+        if (p.scan_mode == 4) p.scan_mode = 0;
+    }
     int variant = V_LDS;
-    if (p.leaf.values) variant = V_LDS;                                // the terminal value lives in the generic kernel
-    else if (p.scan_mode == 4 && chunk) variant = V_CHUNK;
+    if (p.scan_mode == 4 && chunk) variant = V_CHUNK;
     else if (p.scan_mode == 2 && row_cap) variant = V_ROW;
     else if (p.scan_mode == 3 && seg_cap) variant = V_SEG;
     else if (p.scan_mode == 0) {
@@ -971,7 +1002,27 @@ static hipError_t launch_mpc(const KernelParams &p_in, hipStream_t st)
     const unsigned blocks = (unsigned)ceil_div(n, segs);
     // LAT builds: lane features, few wavefronts per SIMD (measured at config 3's shape: -11 % at one per SIMD,
     // -2.6 % at two, -1 % at four, +0.4 % at eight), no diagnostics knob set
-    const bool lat = L > 0 && NO > 0 && !p.no_skips && !p.no_unify && !p.no_latency_build;
+    if constexpr (leaf_fast) {
+        if (leaf && variant == V_SEG && blocks <= 4 * simds) {
+            p.leaf.grid_in_lds = 1;
+            hipLaunchKernelGGL((mpc_kernel<HT, NO, L, V_SEG, true, true>), dim3(blocks), dim3(64), leaf_lds, st, p);
+            return hipGetLastError();
+        }
+        if (leaf && variant == V_ROW && (long long)blocks * K <= simds) {
+            const size_t lds = (size_t)2 * K * G.SEL_FLOATS * sizeof(float) + leaf_lds;
+            p.leaf.grid_in_lds = 1;
+            hipLaunchKernelGGL((mpc_kernel<HT, NO, L, V_ROW, true, true>), dim3(blocks), dim3(64 * K), lds, st, p);
+            return hipGetLastError();
+        }
+    }
+    if (leaf) {                                                        // generic kernel, densest packing
+        p.segs_used = p_in.segs_used > 0 ? clampi(p_in.segs_used, 1, G.SEGS) : clampi(ceil_div(n, cus), 1, G.SEGS);
+        const unsigned gblocks = (unsigned)ceil_div(n, p.segs_used);
+        const size_t base = ((size_t)K * G.WAVE_FLOATS + (size_t)2 * K * G.SEL_FLOATS) * sizeof(float);
+        p.leaf.grid_in_lds = (base + leaf_lds <= 64 * 1024) ? 1 : 0;   // (the default dynamic-LDS limit of a launch)
+        hipLaunchKernelGGL((mpc_kernel<0, NO, L, V_LDS, true>), dim3(gblocks), dim3(64 * K), base + (p.leaf.grid_in_lds ? leaf_lds : 0), st, p);
+        return hipGetLastError();
+    }
     if constexpr (HT > 0) {
         if (variant == V_SEG) {
             if constexpr (HT * 3 <= 64) {
@@ -990,8 +1041,7 @@ static hipError_t launch_mpc(const KernelParams &p_in, hipStream_t st)
         }
     }
     const size_t lds = ((size_t)K * G.WAVE_FLOATS + (size_t)2 * K * G.SEL_FLOATS) * sizeof(float);
-    if (p.leaf.values) hipLaunchKernelGGL((mpc_kernel<0, NO, L, V_LDS, true>), dim3(blocks), dim3(64 * K), lds, st, p);
-    else hipLaunchKernelGGL((mpc_kernel<HT, NO, L, V_LDS>), dim3(blocks), dim3(64 * K), lds, st, p);
+    hipLaunchKernelGGL((mpc_kernel<HT, NO, L, V_LDS>), dim3(blocks), dim3(64 * K), lds, st, p);
     return hipGetLastError();
 }
 

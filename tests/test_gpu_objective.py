@@ -129,6 +129,36 @@ def test_terminal_value_bitwise(oracle, name, H, proj_kind):
         oracle.set_leaf_value(None, None)
 
 
+@pytest.mark.parametrize("H,extra", [(5, False), (6, False), (5, True)])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_terminal_value_every_variant(oracle, H, extra, mode):
+    """The specialised terminal-value builds (V_ROW / V_SEG latency builds at the reference's horizons 5 and 6, the value
+    grid's cell boundaries staged in LDS, table loads issued ahead of the features) and the generic kernel: plans and
+    episodes bit for bit the oracle's, uniform and non-uniform grid axes (one-step corner search / the walk)."""
+    from l4dc_mpc_ocd_amd.engine import Engine
+    scn = scenarios.finite_horizon(horizon=H, n_iter=25, extra_inits=extra)
+    eng = Engine(scn, "cuda:0")
+    eng.set_option("scan_mode", mode)
+    grid, vals = value_table(3 * H + mode)
+    eng.set_leaf_value(grid, vals, 1)
+    oracle.set_leaf_value(grid, vals, 1)
+    try:
+        B = 41
+        ws = world_states(scn, B, seed=H + 11)
+        ws[:3, 0, 1] = 5.0                                       # outside the y grid
+        w = np.stack([scenarios.planner_weights_fp32(c) for c in scn.candidate_weights(B, seed=H + 12)])
+        ref = oracle.plan_batch(scn.desc, ws, w)
+        got = eng.plan_batch(ws, w, want_all=True)
+        same(got["all_losses"], ref["all_losses"], "losses"); same(got["all_plans"], ref["all_plans"], "plans")
+        assert np.array_equal(got["best_init"], ref["best_init"])
+        inits = scn.init_dist.sample(4, seed=5)
+        ro = eng.rollout(inits, w[:3], want_traj=True)
+        rr = oracle.rollout(scn.desc, inits, w[:3], want_traj=True)
+        same(ro["ctrl"], rr["ctrl"], "ctrl"); same(ro["returns"], rr["returns"], "returns")
+    finally:
+        oracle.set_leaf_value(None, None)
+
+
 def test_teleport_cycle_follows_the_flat_episode_index(oracle):
     """ReplanningCarWorld.reset() toggles the removed car on every reset (replanning_world.py:24-27): with one
     sample per init consecutive inits lose different cars, and reset_phase shifts the cycle."""
