@@ -32,20 +32,33 @@ def episode_range(P: int, N: int, S: int, world_size: int, rank: int) -> Tuple[i
     return lo * N * S, hi * N * S
 
 
-def gather_returns(local: torch.Tensor, P: int, N: int, S: int, group: Optional[dist.ProcessGroup] = None
-                   ) -> torch.Tensor:
-    """All-gather the per-episode returns of every rank into the full [P*N*S] vector (on every rank)."""
+_GATHER_BUFS = {}
+
+
+def gather_returns(local: torch.Tensor, P: int, N: int, S: int, group: Optional[dist.ProcessGroup] = None,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """All-gather the per-episode returns of every rank into the full [P*N*S] vector (on every rank).
+    The receive buffer is kept per (device, size) and reused across generations (a generation is ~1.7 ms:
+    allocations are worth avoiding), so the result is valid until the next gather of the same size -- every caller
+    copies it to the host at once.  `out`: a caller-owned [world_size * max_block] buffer instead."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local
     ws = dist.get_world_size(group)
     if local.is_cuda and dist.get_backend(group) == "gloo":
         local = local.cpu()                  # rehearsal backend: gloo gathers host tensors (RCCL takes device memory)
+        out = None
     sizes = [(candidate_block(P, ws, r)[1] - candidate_block(P, ws, r)[0]) * N * S for r in range(ws)]
     m = max(sizes)
     if local.numel() != sizes[dist.get_rank(group)]:
         raise ValueError(f"rank holds {local.numel()} returns, expected {sizes[dist.get_rank(group)]}")
     padded = local if local.numel() == m else torch.cat([local, local.new_zeros(m - local.numel())])
-    out = torch.empty(ws * m, dtype=local.dtype, device=local.device)
+    if out is None or out.numel() != ws * m or out.device != local.device or out.dtype != local.dtype:
+        key = (str(local.device), ws * m, local.dtype)
+        out = _GATHER_BUFS.get(key)
+        if out is None:
+            if len(_GATHER_BUFS) > 16:
+                _GATHER_BUFS.clear()
+            out = _GATHER_BUFS[key] = torch.empty(ws * m, dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, padded.contiguous(), group=group)
     if all(s == m for s in sizes):
         return out
