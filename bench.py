@@ -149,7 +149,8 @@ def plumbing_check(args, world, rank):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"plumbing": True, "n_gpus": world, "torch": torch.__version__}))
+        print(json.dumps({"plumbing": True, "n_gpus": world, "torch": torch.__version__, "scaling": args.scaling,
+                          "emulate_rank": args.emulate_rank or None}))
 
 
 def main():
@@ -179,11 +180,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: world size {world} (WORLD_SIZE) != --gpus {args.gpus}")
-    if args.plumbing_check:
-        return plumbing_check(args, world, rank)
     emulate = parse_emulate(args.emulate_rank) if args.emulate_rank else None
     if emulate and world != 1:
         raise SystemExit("--emulate-rank runs on one GPU (--gpus 1)")
+    if args.plumbing_check:
+        return plumbing_check(args, world, rank)
 
     import torch
     import torch.distributed as dist

@@ -39,3 +39,19 @@ def test_world_size_mismatch_fails():
     r = run(["--gpus", "4", "--plumbing-check"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0
     assert "world size 1" in (r.stderr + r.stdout)
+
+
+def test_strong_scaling_and_rank_emulation_flags():
+    port = 29650 + os.getpid() % 300
+    r = run(["--gpus", "2", "--scaling", "strong", "--plumbing-check", "--master-port", str(port)])
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = last_json(r.stdout)
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong"
+    r = run(["--emulate-rank", "3/8", "--config", "4", "--plumbing-check"])
+    assert r.returncode == 0 and last_json(r.stdout)["emulate_rank"] == "3/8"
+    for bad in ("8/8", "x", "-1/4"):
+        r = run(["--emulate-rank", bad, "--plumbing-check"])
+        assert r.returncode != 0 and "emulate-rank" in (r.stderr + r.stdout)
+    # one rank's block is emulated on ONE GPU: not together with several ranks
+    r = run(["--gpus", "2", "--emulate-rank", "0/8", "--plumbing-check"], env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "one GPU" in (r.stderr + r.stdout)
