@@ -36,10 +36,15 @@ namespace ocd {
 //   ballot -> SALU -> branch stalls (ocd_kernels.hip, LAT).  This build evaluates reward_one unconditionally and
 //   straight-line for every step of the chunk and repairs the rare step with a multi-feature lane out of line.
 //   The diagnostics knobs no_feature_skips / no_unified_features select the LAT = false build.
-template <int HT, int NO, int L, int S, bool LAT = false>
-__global__ void __launch_bounds__(64) OCD_CHUNK_OCC
+// OCC3: compiled for THREE wavefronts per SIMD (<= 168 VGPRs; hipcc spills 20-70 dwords of the per-step tape to
+//   scratch, which three wavefronts hide): launches with at least three full-packed wavefronts per SIMD gain 4-5 %
+//   (config 4 whole 19.6 -> 18.7 ms, config 5 whole 41.0 -> 39.3 ms, 16 x config 3 16.9 -> 16.0 ms); smaller launches
+//   lose 3-4 % and keep the two-wavefront build.  Same code, same results.
+template <int HT, int NO, int L, int S, bool LAT = false, bool OCC3 = false>
+__global__ void __launch_bounds__(64, OCC3 ? 3 : 1) OCD_CHUNK_OCC
 mpc_chunk_kernel(const KernelParams p)
 {
+    static_assert(!(LAT && OCC3), "the latency build runs alone on its SIMD");
     static_assert(HT % S == 0, "the chunk size divides the horizon");
     constexpr int H = HT;
     constexpr int NC = HT / S;                                 // lanes per (trajectory, initialisation)
@@ -548,6 +553,8 @@ static hipError_t launch_chunk(const KernelParams &p_in, hipStream_t st)
     const unsigned blocks = (unsigned)((p.n_problems + segs - 1) / segs);
     const bool lat = L > 0 && NO > 0 && !p.no_skips && !p.no_unify && !p.no_latency_build && (long long)blocks <= simds;
     if (lat) hipLaunchKernelGGL((mpc_chunk_kernel<HT, NO, L, S, true>), dim3(blocks), dim3(64), 0, st, p);
+    else if ((long long)blocks >= 3 * simds && !p.no_latency_build)
+        hipLaunchKernelGGL((mpc_chunk_kernel<HT, NO, L, S, false, true>), dim3(blocks), dim3(64), 0, st, p);
     else hipLaunchKernelGGL((mpc_chunk_kernel<HT, NO, L, S>), dim3(blocks), dim3(64), 0, st, p);
     return hipGetLastError();
 }
