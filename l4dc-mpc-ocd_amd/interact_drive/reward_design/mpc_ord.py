@@ -151,9 +151,9 @@ class MPC_ORD:
         e0, e1 = sharding.episode_range(P, N, S, dist.get_world_size(), dist.get_rank()) if sharded else (0, P * N * S)
         st = self._staging(eng, P, N, S, w32.shape[1], e1 - e0)
         t = self._tick("normalise", t)
-        dev_index = eng.device.index
-        if torch.cuda.current_device() != dev_index:
-            torch.cuda.set_device(dev_index)
+        if torch.cuda.current_device() != eng.device.index:        # rare: run the same body under the engine's device
+            with torch.cuda.device(eng.device):
+                return self._returns(inits, weights_2d, while_running)
         st["w_np"][...] = w32                                      # the kernel reads the pinned rows directly
         stream = torch.cuda.current_stream()
         abi.check(eng.lib, eng.lib.ocd_rollout_episodes(
