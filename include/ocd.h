@@ -165,6 +165,13 @@ void ocd_scenario_destroy(ocd_scenario *scn);
  *                  (see ocd_scenario_desc.teleport_period); default 0. */
 int32_t ocd_scenario_set_option(ocd_scenario *scn, const char *name, int32_t value);
 
+/* Diagnostics: what the most recent planner launch of this handle chose (no counterpart in the reference).
+ * info = {scan mode 1..4 (see "scan_mode"), chunk size (mode 4, else 0), trajectories per wavefront, workgroups,
+ *         wavefronts per SIMD the build was compiled for (1 = the latency build, 0 = unconstrained),
+ *         horizon the kernel is specialised on (0 = run-time horizon), terminal value 0/1, wavefronts per workgroup};
+ * all zero before the first launch. */
+int32_t ocd_scenario_last_launch(const ocd_scenario *scn, int32_t info[8]);
+
 /*
  * Terminal value of the planner: NaivePlanner(leaf_evaluation=ValueFeature(...).interpolate_value(t))
  * (naive_planner.py:20,69-70; reward_design/value_interpolation.py:28-61).  When set, the reward of

@@ -92,6 +92,7 @@ HIP_SYMBOLS = [
     ("ocd_scenario_create", C.c_int32, [C.POINTER(ScenarioDesc), C.POINTER(_VP)]),
     ("ocd_scenario_destroy", None, [_VP]),
     ("ocd_scenario_set_option", C.c_int32, [_VP, C.c_char_p, C.c_int32]),
+    ("ocd_scenario_last_launch", C.c_int32, [_VP, _I]),
     ("ocd_scenario_set_leaf_value", C.c_int32, [_VP, _F, C.c_int32, _F, C.c_int32, _F, C.c_int32, _F, C.c_int32]),
     ("ocd_plan_batch", C.c_int32,
      [_VP, _VP, _VP, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, _VP]),

@@ -36,6 +36,7 @@ struct ocd_scenario {
     int32_t leaf_proj = 0;
     float *dev_leaf[OCD_MAX_DEVICES];
     int32_t n_cus[OCD_MAX_DEVICES];
+    mutable int32_t last_launch[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ocd_scenario_last_launch (guarded by mu)
 };
 
 #ifdef OCD_STAMPS
@@ -173,7 +174,13 @@ int32_t launch(const ocd_scenario *scn, ocd::KernelParams &p, void *hip_stream)
 #endif
     bool supported = false;
     const int L = kernel_L(scn->desc);
+    int32_t info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    p.launch_info = info;
     hipError_t e = ocd::launch_mpc_dispatch(scn->desc.horizon, scn->desc.n_cars - 1, L, p, (hipStream_t)hip_stream, &supported);
+    {
+        std::lock_guard<std::mutex> lock(const_cast<ocd_scenario *>(scn)->mu);
+        std::memcpy(scn->last_launch, info, sizeof(info));
+    }
     if (!supported)
         return fail(OCD_ERR_UNSUPPORTED, "no compiled kernel for horizon %d with %d scripted cars and %d lanes (see OCD_PAIR_TABLE)",
                     scn->desc.horizon, scn->desc.n_cars - 1, L);
@@ -225,6 +232,14 @@ int32_t ocd_scenario_set_option(ocd_scenario *scn, const char *name, int32_t val
         return OCD_OK;
     }
     return fail(OCD_ERR_INVALID_ARG, "unknown option '%s'", name);
+}
+
+int32_t ocd_scenario_last_launch(const ocd_scenario *scn, int32_t info[8])
+{
+    if (!scn || !info) return fail(OCD_ERR_INVALID_ARG, "scenario or info is NULL");
+    std::lock_guard<std::mutex> lock(const_cast<ocd_scenario *>(scn)->mu);
+    std::memcpy(info, scn->last_launch, sizeof(scn->last_launch));
+    return OCD_OK;
 }
 
 int32_t ocd_scenario_set_leaf_value(ocd_scenario *scn, const float *grid0, int32_t n0,

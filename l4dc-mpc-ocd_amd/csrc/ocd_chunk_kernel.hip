@@ -41,13 +41,17 @@ namespace ocd {
 //   (config 4 whole 19.6 -> 18.7 ms, config 5 whole 41.0 -> 39.3 ms, 16 x config 3 16.9 -> 16.0 ms); smaller launches
 //   lose 3-4 % and keep the two-wavefront build.  Same code, same results.
 template <int HT, int NO, int L, int S, bool LAT = false, bool OCC3 = false>
-__global__ void __launch_bounds__(64, OCC3 ? 3 : 1) OCD_CHUNK_OCC
+__global__ void __launch_bounds__(64, OCC3 ? (S <= 2 ? 4 : 3) : 1) OCD_CHUNK_OCC
 mpc_chunk_kernel(const KernelParams p)
 {
     static_assert(!(LAT && OCC3), "the latency build runs alone on its SIMD");
-    static_assert(HT % S == 0, "the chunk size divides the horizon");
     constexpr int H = HT;
-    constexpr int NC = HT / S;                                 // lanes per (trajectory, initialisation)
+    constexpr int NC = (HT + S - 1) / S;                       // lanes per (trajectory, initialisation)
+    // steps of a segment's LAST lane; S does not have to divide H: the rest of that lane's chunk is padding ("dead"
+    // steps s >= SL): evaluated with the wavefront, kept out of its feature decisions, and entered on the tape as
+    // zeros (zero step length, zero feature adjoint), which leaves every adjoint at the +0 it starts from
+    constexpr int SL = HT - (NC - 1) * S;
+    static_assert(SL >= 1 && SL <= S, "the last lane owns at least one step");
     constexpr int NOA = NO > 0 ? NO : 1;
     constexpr bool lane_feats = L > 0;
     constexpr int D = feat_dim(L);
@@ -64,6 +68,7 @@ mpc_chunk_kernel(const KernelParams p)
     const bool live = (slot < p.segs_used) && (prob_raw < p.n_problems);
     const long long prob = live ? prob_raw : (p.n_problems - 1);   // parked lanes shadow a real problem
     const unsigned long long live_mask = __ballot(live);
+    const unsigned long long real_mask = live_mask & ~__ballot(last);   // the lanes whose padding steps (if any) count
 
     const float dt = d.dt, dt2 = d.dt_sq, fr = d.ego_friction, lr = d.learning_rate;
 
@@ -257,6 +262,10 @@ mpc_chunk_kernel(const KernelParams p)
                     vn[s] = v;
                     sincos_(th, sn[s], cn[s]);
                 }
+                if constexpr (SL < S) {
+#pragma unroll
+                    for (int s = SL; s < S; ++s) { dd[s] = last ? 0.0f : dd[s]; vpre[s] = last ? 0.0f : vpre[s]; }
+                }
             }
             // sin / cos of the heading BEFORE each step: the previous step's, across the lane boundary for s = 0
             float s_pre[S], c_pre[S];
@@ -266,6 +275,10 @@ mpc_chunk_kernel(const KernelParams p)
                 c_pre[0] = first ? c0 : cb;
 #pragma unroll
                 for (int s = 1; s < S; ++s) { s_pre[s] = sn[s - 1]; c_pre[s] = cn[s - 1]; }
+                if constexpr (SL < S) {                        // padding steps: an all-zero tape entry
+#pragma unroll
+                    for (int s = SL; s < S; ++s) { s_pre[s] = last ? 0.0f : s_pre[s]; c_pre[s] = last ? 0.0f : c_pre[s]; }
+                }
             }
             float cd[S], sd[S];
 #pragma unroll
@@ -300,14 +313,15 @@ mpc_chunk_kernel(const KernelParams p)
                     bool nc[NOA];
                     nc[0] = false;
                     const bool nf = needs_fence(d, xn);
-                    const unsigned long long mf = __builtin_amdgcn_ballot_w64(nf) & live_mask;
+                    const unsigned long long lm = (s >= SL) ? real_mask : live_mask;
+                    const unsigned long long mf = __builtin_amdgcn_ballot_w64(nf) & lm;
                     unsigned long long mc_any = 0ull, multi_f = 0ull, multi_c = 0ull;
 #pragma unroll
                     for (int j = 0; j < NO; ++j) {
                         const float dx = xn - bg[s][j].cx, dy = yn - bg[s][j].cy;
                         const bool ncx = __builtin_fabsf(dx) < wx1[s][j], ncy = __builtin_fabsf(dy) < wy1[s][j];
                         nc[j] = ncx && ncy;
-                        const unsigned long long mj = __builtin_amdgcn_ballot_w64(ncx) & __builtin_amdgcn_ballot_w64(ncy) & live_mask;
+                        const unsigned long long mj = __builtin_amdgcn_ballot_w64(ncx) & __builtin_amdgcn_ballot_w64(ncy) & lm;
                         multi_f |= (mj & mf);
                         multi_c |= (mj & mc_any);
                         mc_any |= mj;
@@ -321,8 +335,11 @@ mpc_chunk_kernel(const KernelParams p)
                         OCD_STAMP(5); OCD_STAMP_COUNT(12);
                     } else {
                         rw[s] = reward_one<NO, L, GRAD, false>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], nc, nf, true, true,
-                                                               q[s], pkc, lgc, live_mask);
+                                                               q[s], pkc, lgc, lm);
                         OCD_STAMP(6); OCD_STAMP_COUNT(13);
+                    }
+                    if constexpr (GRAD) {
+                        if (s >= SL) { q[s].qx = last ? 0.0f : q[s].qx; q[s].qy = last ? 0.0f : q[s].qy; q[s].qv = last ? 0.0f : q[s].qv; q[s].qth = last ? 0.0f : q[s].qth; }
                     }
                 }
             } else {
@@ -336,12 +353,13 @@ mpc_chunk_kernel(const KernelParams p)
                         bool nc[NOA];
                         nc[0] = false;
                         const bool nf = needs_fence(d, xn);
-                        unsigned long long mf = __ballot(nf) & live_mask, mc_any = 0ull, multi_f = 0ull, multi_c = 0ull;
+                        const unsigned long long lm = (s >= SL) ? real_mask : live_mask;
+                        unsigned long long mf = __ballot(nf) & lm, mc_any = 0ull, multi_f = 0ull, multi_c = 0ull;
 #pragma unroll
                         for (int j = 0; j < NO; ++j) {
                             const float dx = xn - bg[s][j].cx, dy = yn - bg[s][j].cy;
                             nc[j] = (__builtin_fabsf(dx) < wx1[s][j]) && (__builtin_fabsf(dy) < wy1[s][j]);
-                            const unsigned long long mj = __ballot(nc[j]) & live_mask;
+                            const unsigned long long mj = __ballot(nc[j]) & lm;
                             multi_f |= (mj & mf);          // fence and a car on one lane
                             multi_c |= (mj & mc_any);      // two cars on one lane
                             mc_any |= mj;
@@ -355,7 +373,7 @@ mpc_chunk_kernel(const KernelParams p)
                             rw[s] = reward_fc<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], nc, q[s], pkc);
                             OCD_STAMP(5); OCD_STAMP_COUNT(12);
                         } else if (has_f || has_col) {
-                            rw[s] = reward_one<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], nc, nf, has_col, has_f, q[s], pkc, lgc, live_mask);
+                            rw[s] = reward_one<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], nc, nf, has_col, has_f, q[s], pkc, lgc, lm);
                             OCD_STAMP(6); OCD_STAMP_COUNT(13);
                             if (has_col) OCD_STAMP_COUNT(11);
                             if (has_f) OCD_STAMP_COUNT(15);
@@ -365,6 +383,9 @@ mpc_chunk_kernel(const KernelParams p)
                         }
                     } else {
                         rw[s] = reward_state<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], q[s], nullptr);
+                    }
+                    if constexpr (GRAD) {
+                        if (s >= SL) { q[s].qx = last ? 0.0f : q[s].qx; q[s].qy = last ? 0.0f : q[s].qy; q[s].qv = last ? 0.0f : q[s].qv; q[s].qth = last ? 0.0f : q[s].qth; }
                     }
                 }
             }
@@ -377,7 +398,7 @@ mpc_chunk_kernel(const KernelParams p)
                 for (int r = 0; r < NC; ++r) {
                     R = Rs;
 #pragma unroll
-                    for (int s = 0; s < S; ++s) R = R + rw[s];
+                    for (int s = 0; s < S; ++s) R = (s >= SL && last) ? R : (R + rw[s]);
                     if (r < NC - 1) {
                         const float Rb = wave_below(R);
                         Rs = first ? 0.0f : Rb;
@@ -464,6 +485,7 @@ mpc_chunk_kernel(const KernelParams p)
             if (p.all_plans_out) {
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
+                    if (c * S + s >= H) continue;
                     float *o = p.all_plans_out + (((size_t)prob * K + kinit) * H + (c * S + s)) * 2;
                     o[0] = ua[s]; o[1] = uw[s];
                 }
@@ -486,6 +508,7 @@ mpc_chunk_kernel(const KernelParams p)
             if (live && kinit == best) {
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
+                    if (c * S + s >= H) continue;
                     float *o = p.plans_out + ((size_t)prob * H + (c * S + s)) * 2;
                     o[0] = ua[s]; o[1] = uw[s];
                 }
@@ -540,7 +563,7 @@ template <int HT, int NO, int L, int S>
 static hipError_t launch_chunk(const KernelParams &p_in, hipStream_t st)
 {
     KernelParams p = p_in;
-    constexpr int NC = HT / S;
+    constexpr int NC = (HT + S - 1) / S;
     const int cap = 64 / (p.K * NC);                            // trajectories per wavefront
     if (cap < 1) return hipErrorInvalidConfiguration;
     const long long simds = 4ll * (p.n_cus > 0 ? p.n_cus : 256);
@@ -552,24 +575,31 @@ static hipError_t launch_chunk(const KernelParams &p_in, hipStream_t st)
     p.segs_used = segs;
     const unsigned blocks = (unsigned)((p.n_problems + segs - 1) / segs);
     const bool lat = L > 0 && NO > 0 && !p.no_skips && !p.no_unify && !p.no_latency_build && (long long)blocks <= simds;
+    const bool occ3 = !lat && (long long)blocks >= 3 * simds && !p.no_latency_build;
+    note_launch(p, 4, S, segs, blocks, lat ? 1 : (occ3 ? 3 : 0), HT, 0, 1);
     if (lat) hipLaunchKernelGGL((mpc_chunk_kernel<HT, NO, L, S, true>), dim3(blocks), dim3(64), 0, st, p);
-    else if ((long long)blocks >= 3 * simds && !p.no_latency_build)
-        hipLaunchKernelGGL((mpc_chunk_kernel<HT, NO, L, S, false, true>), dim3(blocks), dim3(64), 0, st, p);
+    else if (occ3) hipLaunchKernelGGL((mpc_chunk_kernel<HT, NO, L, S, false, true>), dim3(blocks), dim3(64), 0, st, p);
     else hipLaunchKernelGGL((mpc_chunk_kernel<HT, NO, L, S>), dim3(blocks), dim3(64), 0, st, p);
     return hipGetLastError();
 }
 
-// cost estimate of chunk size S for n trajectories: full rounds of wavefronts x instructions per pass
-static double chunk_cost(int H, int K, int NO, int S, long long n, long long slots)
+// Cost of chunk size S for n trajectories (round-3 sweeps, tools/sweep_sizes.sh, profiles/r03_sweep_sizes.txt):
+//   instructions per pass of a wavefront ~ A(H) + B(NO) * S  (A: the recurrence rounds and the per-pass fixed part,
+//   B: the lane-parallel work of one step), measured 430 / 730 / 1 330 at H = 10 / 15 / 25 and 350 / 550 per step with
+//   one / two scripted cars;
+//   a SIMD with w wavefronts needs w / g(w) times a lone wavefront's time, g = 1, 1.19, 1.26, 1.31 ... 1.41 at 8 (the
+//   issue table of DESIGN.md section 4); a launch lasts as long as its busiest SIMD: w = ceil(wavefronts / SIMDs).
+static double chunk_cost(int H, int K, int NO, int S, long long n, long long simds)
 {
-    const int NC = H / S;
+    const int NC = (H + S - 1) / S;
     const int cap = 64 / (K * NC);
     if (cap < 1) return 1e30;
     const long long waves = (n + cap - 1) / cap;
-    const long long rounds = (waves + slots - 1) / slots;
-    // recurrences + lane-parallel work per step (instructions; more scripted cars = more feature work)
-    const double per_pass = (double)(NC - 1) * S * 20.0 + S * (350.0 + 200.0 * (NO > 1 ? NO - 1 : 0)) + 60.0;
-    return (double)(rounds < 1 ? 1 : rounds) * per_pass;
+    const long long w = waves <= simds ? 1 : (waves + simds - 1) / simds;
+    static const double g[9] = {1.0, 1.0, 1.19, 1.26, 1.31, 1.33, 1.36, 1.38, 1.41};
+    const double a = 60.0 * H - 170.0;
+    const double per_pass = (a < 200.0 ? 200.0 : a) + S * (350.0 + 200.0 * (NO > 1 ? NO - 1 : 0));
+    return per_pass * (double)w / g[w > 8 ? 8 : w];
 }
 
 #define OCD_CPICK(HH, NN, LL, SS)                                                                         \
@@ -582,8 +612,7 @@ static double chunk_cost(int H, int K, int NO, int S, long long n, long long slo
 hipError_t launch_chunk_dispatch(int H, int NO, int L, const KernelParams &p, hipStream_t st, bool launch, int want,
                                  int *chunk)
 {
-    // two wavefronts per SIMD fit (190-235 VGPRs)
-    const long long slots = 2ll * 4ll * (p.n_cus > 0 ? p.n_cus : 256);
+    const long long slots = 4ll * (p.n_cus > 0 ? p.n_cus : 256);   // SIMDs
     int best = 0;
     double best_cost = 1e29;
     OCD_CHUNK_TABLE(OCD_CPICK)

@@ -69,7 +69,20 @@ struct KernelParams {
     int32_t chunk_size;        // V_CHUNK: 0 = pick the compiled chunk size by cost, else force this one
     int32_t n_cus;             // compute units of the device (launch shape heuristics)
     unsigned long long *debug; // diagnostic builds only (OCD_STAMPS): per-wavefront cycle totals, else nullptr
+    int32_t *launch_info;      // HOST pointer or nullptr: the launcher records its choice here (ocd_scenario_last_launch)
 };
+
+// what a launch chose: {scan mode 1..4, chunk size S (V_CHUNK) else 0, trajectories per wavefront, workgroups,
+// wavefronts per SIMD the build is compiled for (1 = the latency build LAT, 0 = unconstrained), H specialised (0 =
+// run-time H), terminal value 0/1, wavefronts per workgroup}
+static inline void note_launch(const KernelParams &p, int mode, int chunk, int segs, unsigned blocks, int build_waves,
+                               int ht, int leaf, int waves_per_group)
+{
+    if (!p.launch_info) return;
+    int32_t *o = p.launch_info;
+    o[0] = mode; o[1] = chunk; o[2] = segs; o[3] = (int32_t)blocks; o[4] = build_waves; o[5] = ht; o[6] = leaf;
+    o[7] = waves_per_group;
+}
 
 // (horizon H, scripted cars NO, lanes L) triples with a planner kernel specialised on H (loops fully
 // unrolled, all three exchange variants).  Horizons 5/6: the reference's own settings; 10/15/25:
@@ -91,11 +104,13 @@ struct KernelParams {
     X(2, 1) X(2, 2) X(2, 3) X(2, 4)                                                           \
     X(3, 1) X(3, 2) X(3, 3) X(3, 4)
 
-// (horizon H, scripted cars NO, lanes L, chunk S) with a chunked kernel (V_CHUNK); several S per shape allowed
+// (horizon H, scripted cars NO, lanes L, chunk S) with a chunked kernel (V_CHUNK); several S per shape; S need not
+// divide H (the last lane of a segment then owns fewer steps).  Small S: more wavefronts of fewer instructions each --
+// the best size is the smallest one whose wavefronts still fit one per SIMD (launch_chunk_dispatch picks by cost).
 #define OCD_CHUNK_TABLE(X)                                                                    \
-    X(10, 1, 3, 5) X(15, 1, 3, 5) X(15, 1, 3, 3) X(25, 1, 3, 5)                               \
-    X(10, 2, 2, 5) X(15, 2, 2, 5) X(15, 2, 2, 3)                                              \
-    X(10, 2, 3, 5) X(25, 2, 3, 5)
+    X(10, 1, 3, 2) X(10, 1, 3, 5) X(15, 1, 3, 2) X(15, 1, 3, 3) X(15, 1, 3, 5) X(25, 1, 3, 3) X(25, 1, 3, 5) \
+    X(10, 2, 2, 2) X(10, 2, 2, 5) X(15, 2, 2, 2) X(15, 2, 2, 3) X(15, 2, 2, 5)                \
+    X(10, 2, 3, 2) X(10, 2, 3, 5) X(25, 2, 3, 3) X(25, 2, 3, 5)
 
 // (H, NO, L) with V_ROW / V_SEG LAT builds that carry the terminal value: the reference's own horizons on the shape
 // its value grids are made for (coarse_value_iteration.py: the three-lane finite-horizon world)

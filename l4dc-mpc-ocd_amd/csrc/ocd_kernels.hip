@@ -942,9 +942,9 @@ static int clampi(long long v, long long lo, long long hi) { return (int)(v < lo
 //     feature skips alone; K wavefronts meet once per control step);
 //   * V_SEG (single-wavefront workgroups spread evenly over the SIMDs, no workgroup barrier) while it gives
 //     at most one wavefront per SIMD, or up to four when it packs lanes as densely as V_LDS (K*H close to 64);
-//   * V_CHUNK once its wavefronts (S times the problems each, spread over the SIMDs first) beat the others: at
-//     H >= 20, where the O(H^2) recurrence work it removes dominates, whenever V_LDS would need more than one
-//     wavefront per SIMD; from one full-packed wavefront per SIMD at H >= 15, 4/5 of that below;
+//   * V_CHUNK (where compiled) as soon as V_LDS would need more than one wavefront per SIMD: a lane owns S steps,
+//     the wavefront S times the trajectories; launch_chunk_dispatch picks S by cost -- in effect the smallest compiled S
+//     whose wavefronts fit one per SIMD, then the one with the least work on the busiest SIMD;
 //   * else V_LDS, densest packing at one lane per step, LDS latency hidden by the other wavefronts.
 // scan_mode 1..4 and segs_per_wave force the choice (tests, sweeps).
 template <int HT, int NO, int L>
@@ -960,7 +960,7 @@ static hipError_t launch_mpc(const KernelParams &p_in, hipStream_t st)
     const int row_cap = (HT > 0 && H <= 16) ? 4 : 0;                   // V_ROW
     int chunk = 0;                                                     // V_CHUNK: chunk size compiled for this shape
     (void)launch_chunk_dispatch(H, NO, L, p, st, false, p.chunk_size, &chunk);
-    if (chunk && 64 / (K * (H / chunk)) < 1) chunk = 0;
+    if (chunk && 64 / (K * ceil_div(H, chunk)) < 1) chunk = 0;
     // terminal value: the generic kernel (run-time H, V_LDS) for every shape; V_ROW / V_SEG LAT builds for the shapes of
     // OCD_LEAF_TABLE while the batch is small enough for them (they are latency builds) and no diagnostics knob is set
     constexpr bool leaf_fast = leaf_specialised<HT, NO, L>::value;
@@ -981,12 +981,12 @@ static hipError_t launch_mpc(const KernelParams &p_in, hipStream_t st)
     else if (p.scan_mode == 0) {
         const long long waves_seg = seg_cap ? ceil_div(n, seg_cap) : 0;
         const long long waves_lds = ceil_div(n, G.SEGS) * K;
-        const long long waves_chunk = chunk ? ceil_div(n, 64 / (K * (H / chunk))) : 0;
-        // (round-3 sweeps, tools/sweep_sizes.sh: with its wavefronts spread over the SIMDs first the chunked mapping wins
-        //  at H >= 20 as soon as V_LDS would put more than one wavefront on a SIMD, at H = 15 from one full-packed
-        //  wavefront per SIMD, at H = 10 from 4/5 of that -- 8 192 episodes of config 3's shape)
-        const long long chunk_from = (H >= 20) ? 0 : ((H >= 15) ? simds : (4 * simds) / 5);
-        const bool chunk_wins = chunk && waves_chunk >= chunk_from && waves_lds > simds;
+        const long long waves_chunk = chunk ? ceil_div(n, 64 / (K * ceil_div(H, chunk))) : 0;
+        // (round-3 sweeps, tools/sweep_sizes.sh: once the one-lane-per-step mappings need a second wavefront on a SIMD,
+        //  the chunked mapping with the smallest chunk that still fits one wavefront per SIMD is ahead at every horizon;
+        //  the one exception found, 6 144 trajectories at H = 10 where V_LDS is 7 % faster, is not worth a rule)
+        const bool chunk_wins = chunk && waves_lds > simds;
+        (void)waves_chunk;
         if (row_cap && n * K <= simds) variant = V_ROW;
         else if (seg_cap && waves_seg <= simds) variant = V_SEG;
         else if (chunk_wins) variant = V_CHUNK;
@@ -1005,12 +1005,14 @@ static hipError_t launch_mpc(const KernelParams &p_in, hipStream_t st)
     if constexpr (leaf_fast) {
         if (leaf && variant == V_SEG && blocks <= 4 * simds) {
             p.leaf.grid_in_lds = 1;
+            note_launch(p, 3, 0, segs, blocks, 1, HT, 1, 1);
             hipLaunchKernelGGL((mpc_kernel<HT, NO, L, V_SEG, true, true>), dim3(blocks), dim3(64), leaf_lds, st, p);
             return hipGetLastError();
         }
         if (leaf && variant == V_ROW && (long long)blocks * K <= simds) {
             const size_t lds = (size_t)2 * K * G.SEL_FLOATS * sizeof(float) + leaf_lds;
             p.leaf.grid_in_lds = 1;
+            note_launch(p, 2, 0, segs, blocks, 1, HT, 1, K);
             hipLaunchKernelGGL((mpc_kernel<HT, NO, L, V_ROW, true, true>), dim3(blocks), dim3(64 * K), lds, st, p);
             return hipGetLastError();
         }
@@ -1020,12 +1022,14 @@ static hipError_t launch_mpc(const KernelParams &p_in, hipStream_t st)
         const unsigned gblocks = (unsigned)ceil_div(n, p.segs_used);
         const size_t base = ((size_t)K * G.WAVE_FLOATS + (size_t)2 * K * G.SEL_FLOATS) * sizeof(float);
         p.leaf.grid_in_lds = (base + leaf_lds <= 64 * 1024) ? 1 : 0;   // (the default dynamic-LDS limit of a launch)
+        note_launch(p, 1, 0, p.segs_used, gblocks, 0, 0, 1, K);
         hipLaunchKernelGGL((mpc_kernel<0, NO, L, V_LDS, true>), dim3(gblocks), dim3(64 * K), base + (p.leaf.grid_in_lds ? leaf_lds : 0), st, p);
         return hipGetLastError();
     }
     if constexpr (HT > 0) {
         if (variant == V_SEG) {
             if constexpr (HT * 3 <= 64) {
+                note_launch(p, 3, 0, segs, blocks, (lat && blocks <= 4 * simds) ? 1 : 0, HT, 0, 1);
                 if (lat && blocks <= 4 * simds) hipLaunchKernelGGL((mpc_kernel<HT, NO, L, V_SEG, false, true>), dim3(blocks), dim3(64), 0, st, p);
                 else hipLaunchKernelGGL((mpc_kernel<HT, NO, L, V_SEG>), dim3(blocks), dim3(64), 0, st, p);
             }
@@ -1034,6 +1038,7 @@ static hipError_t launch_mpc(const KernelParams &p_in, hipStream_t st)
         if (variant == V_ROW) {
             const size_t lds = (size_t)2 * K * G.SEL_FLOATS * sizeof(float);
             if constexpr (HT <= 16) {
+                note_launch(p, 2, 0, segs, blocks, (lat && (long long)blocks * K <= simds) ? 1 : 0, HT, 0, K);
                 if (lat && (long long)blocks * K <= simds) hipLaunchKernelGGL((mpc_kernel<HT, NO, L, V_ROW, false, true>), dim3(blocks), dim3(64 * K), lds, st, p);
                 else hipLaunchKernelGGL((mpc_kernel<HT, NO, L, V_ROW>), dim3(blocks), dim3(64 * K), lds, st, p);
             }
@@ -1041,6 +1046,7 @@ static hipError_t launch_mpc(const KernelParams &p_in, hipStream_t st)
         }
     }
     const size_t lds = ((size_t)K * G.WAVE_FLOATS + (size_t)2 * K * G.SEL_FLOATS) * sizeof(float);
+    note_launch(p, 1, 0, segs, blocks, 0, HT, 0, K);
     hipLaunchKernelGGL((mpc_kernel<HT, NO, L, V_LDS>), dim3(blocks), dim3(64 * K), lds, st, p);
     return hipGetLastError();
 }

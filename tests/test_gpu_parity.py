@@ -216,6 +216,48 @@ def test_all_scan_variants_bitwise(oracle, eng_factory, hip, scan_mode, name, H,
     assert_bitwise(ro["returns"], rr["returns"], "returns")
 
 
+@pytest.mark.parametrize("name,H,chunk", [("finite_horizon", 10, 2), ("finite_horizon", 10, 5), ("local_opt", 15, 2),
+                                          ("local_opt", 15, 3), ("local_opt", 15, 5), ("replanning", 15, 2),
+                                          ("replanning", 15, 3), ("replanning", 10, 2), ("replanning", 10, 5),
+                                          ("merging", 25, 3), ("merging", 25, 5), ("local_opt", 25, 3),
+                                          ("merging", 10, 2)])
+def test_chunk_sizes_bitwise(oracle, eng_factory, hip, name, H, chunk):
+    """V_CHUNK with every compiled chunk size S, including sizes that do not divide the horizon (the last lane of a
+    segment then owns H - (NC-1)*S steps and padding): latency build, throughput build (no_latency_build), the
+    three-wavefront build (a launch of >= 3 wavefronts per SIMD is too big for a test; its code differs only in
+    register allocation), full and partial packing, an overflowing problem among the others."""
+    scn = scenarios.SCENARIOS[name](horizon=H, n_iter=18)
+    eng = eng_factory(scn)
+    B = 23
+    ws = _world_states(scn, B, seed=H + chunk)
+    ws[5, 0, 2] = -40.0                                   # overflows inside the horizon
+    w = np.stack([scenarios.planner_weights_fp32(c) for c in scn.candidate_weights(B, seed=H + 4)])
+    ref = oracle.plan_batch(scn.desc, ws, w, other_plans=scn.other_plans())
+    inits = scn.init_dist.sample(3, seed=H + 5)
+    rr = oracle.rollout(scn.desc, inits, w[:2], want_traj=True)
+    eng.set_option("scan_mode", 4)
+    eng.set_option("chunk_size", chunk)
+    try:
+        outs = []
+        for segs, nolat in ((0, 0), (1, 0), (0, 1), (2, 1)):
+            eng.set_option("segs_per_wave", segs)
+            eng.set_option("no_latency_build", nolat)
+            outs.append(eng.plan_batch(ws, w, want_all=True))
+            ll = eng.last_launch()
+            assert (ll["scan_mode"], ll["chunk"], ll["specialised_horizon"]) == (4, chunk, H), ll
+            assert ll["build_wavefronts_per_simd"] == (0 if nolat else 1) and (segs == 0 or ll["trajectories_per_wavefront"] == segs)
+            ro = eng.rollout(inits, w[:2], want_traj=True)
+            assert_bitwise(ro["ctrl"], rr["ctrl"], "controls"); assert_bitwise(ro["traj"], rr["traj"], "traj")
+            assert_bitwise(ro["returns"], rr["returns"], "returns")
+    finally:
+        eng.set_option("scan_mode", 0); eng.set_option("chunk_size", 0)
+        eng.set_option("segs_per_wave", 0); eng.set_option("no_latency_build", 0)
+    for o in outs:
+        assert_bitwise(o["all_losses"], ref["all_losses"], "losses"); assert_bitwise(o["all_plans"], ref["all_plans"], "plans")
+        assert np.array_equal(o["best_init"], ref["best_init"]); assert_bitwise(o["best_loss"], ref["best_loss"], "best loss")
+        assert_bitwise(o["plans"], ref["plans"], "plans")
+
+
 @pytest.mark.parametrize("segs,mode", [(1, 0), (2, 0), (6, 1), (0, 0), (1, 3), (2, 3), (3, 2), (0, 4), (3, 4), (1, 4)])
 def test_results_do_not_depend_on_packing(oracle, eng_factory, hip, segs, mode):
     """segs_per_wave (trajectories per wavefront) is a pure performance knob: packed lanes, parked

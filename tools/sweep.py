@@ -10,6 +10,12 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+def launch_tag(eng):
+    ll = eng.last_launch()
+    return (f"[{ll['mapping']}" + (f" S={ll['chunk']}" if ll["chunk"] else "") + f" x{ll['trajectories_per_wavefront']}"
+            f" wg={ll['workgroups']}x{ll['wavefronts_per_workgroup']} build={ll['build_wavefronts_per_simd']}]")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", default="2")
@@ -43,18 +49,18 @@ def main():
         eng.set_option("no_latency_build", a.no_lat)
         for mode in [int(m) for m in a.scan_mode.split(",")]:
             if (mode == 2 and c["horizon"] > 16) or (mode == 3 and scn.desc.n_ctrl_inits * c["horizon"] > 64) or \
-                    (mode == 4 and c["horizon"] % 5):
+                    (mode == 4 and not a.chunk and c["horizon"] % 5):
                 continue
             eng.set_option("scan_mode", mode)
             for segs in [int(s) for s in a.segs.split(",")]:
                 if (mode == 2 and segs > 4) or (mode == 3 and segs > 64 // (scn.desc.n_ctrl_inits * c["horizon"])) or \
-                        (mode == 4 and segs > 64 // (scn.desc.n_ctrl_inits * (c["horizon"] // (a.chunk or 5)))):
+                        (mode == 4 and segs > 64 // (scn.desc.n_ctrl_inits * -(-c["horizon"] // (a.chunk or 5)))):
                     continue
                 eng.set_option("segs_per_wave", segs)
                 eng.time_rollout(init_dev, w_dev, 0, E, ret, 1)
                 ms = eng.time_rollout(init_dev, w_dev, 0, E, ret, a.reps)
                 print(f"cfg{cfg} {c['scenario']} H={c['horizon']} E={E} scan_mode={mode} segs={segs}: {ms:.3f} ms/launch "
-                      f"-> {E / ms * 1e3:.0f} episodes/s  checksum {float(ret.sum()):.6f}", flush=True)
+                      f"-> {E / ms * 1e3:.0f} episodes/s  checksum {float(ret.sum()):.6f}  {launch_tag(eng)}", flush=True)
 
 
 if __name__ == "__main__":
