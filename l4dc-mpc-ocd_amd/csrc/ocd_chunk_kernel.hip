@@ -110,6 +110,14 @@ mpc_chunk_kernel(const KernelParams p)
 
     const int T = p.T;
     const PkConsts pkc = pk_consts();
+    // The latency build wants its SIMD to itself, and the workgroup dispatcher does not promise that: in the diagnostic
+    // build (make stamps; a third of the register file per wavefront) it put two of the 1 024 single-wavefront
+    // workgroups on every tenth SIMD and none on as many others, and those wavefronts took 1.5x as long
+    // (tools/stamp_profile.py prints the placement from HW_ID).  Claiming the accumulation registers -- never touched,
+    // the clobber only raises the kernel's register allocation above half of the SIMD's 512 -- makes a second wavefront
+    // on a SIMD impossible, so the dispatcher has to use every SIMD.  (The product build timed the same before and
+    // after: it was being placed evenly; this makes that a property of the kernel instead of luck.)
+    if constexpr (LAT) asm volatile("" ::: "a255");
     OCD_STAMP_DECL
     float G_ret = 0.0f;
     const BumpGeom bg0 = {0.0f, 1.0f, 0.0f, 1.0f};
@@ -329,7 +337,7 @@ mpc_chunk_kernel(const KernelParams p)
                     OCD_STAMP(4);                          // choice of the evaluation
                     if (__builtin_expect((multi_f | multi_c) != 0ull, 0)) {
                         if (multi_c != 0ull)
-                            rw[s] = reward_state<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], q[s], nullptr, true, true);
+                            rw[s] = reward_every<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], q[s], pkc);
                         else
                             rw[s] = reward_fc<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], nc, q[s], pkc);
                         OCD_STAMP(5); OCD_STAMP_COUNT(12);
@@ -367,6 +375,7 @@ mpc_chunk_kernel(const KernelParams p)
                         const bool has_f = mf != 0ull, has_col = mc_any != 0ull;
                         OCD_STAMP(4);                      // choice of the evaluation
                         if (p.no_skips || multi_c != 0ull || (p.no_unify && (has_f || has_col))) {
+                            // (reward_every's packed form needs more registers than these builds have to spare)
                             rw[s] = reward_state<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], q[s], nullptr, true, true);
                             OCD_STAMP(5); OCD_STAMP_COUNT(12);
                         } else if (multi_f != 0ull) {
@@ -553,6 +562,12 @@ mpc_chunk_kernel(const KernelParams p)
     if (p.mode == OCD_MODE_ROLLOUT && writer) p.returns_out[prob] = G_ret;
 #ifdef OCD_STAMPS
     OCD_STAMP(0);
+    if constexpr (LAT) {                                       // (slot 14 counts a path the latency build does not have)
+        unsigned hw, xcc;                                      // where this wavefront ran: HW_ID | XCC_ID << 32
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        st_acc[14] = (unsigned long long)hw | ((unsigned long long)(xcc & 0xf) << 32) | (1ull << 40);
+    }
     if (p.debug && lane == 0)
         for (int i = 0; i < 16; ++i) p.debug[(size_t)blockIdx.x * 16 + i] = st_acc[i];
 #endif

@@ -473,6 +473,154 @@ __device__ __forceinline__ float reward_fc(const ocd_scenario_desc &d, const flo
     return r;
 }
 
+// ---------------------------------------------------------------- reward, fence + BOTH scripted cars (NO == 2)
+// reward_state<2, L, GRAD>(..., do_col = true, do_fence = true) with its divisions and exponentials two-wide: the x
+// bump units of the two cars are one packed pair, their y units another, the fence's two _f units a third (as in
+// reward_fc).  No precondition: every feature of every lane is evaluated, same operations on the same values in the
+// same order as reward_state (the packed instructions are element-wise; bump_bwd loses its head select exactly as in
+// reward_fc).  11 packed + 1 scalar divisions and 3 packed exponentials per lane-step instead of 23 + 6 scalar ones:
+// this is the evaluation of a pass in which some lane sits inside BOTH cars' collision boxes -- most passes of the
+// slowest wavefronts of the replanning scenario, whose two scripted cars start at the same place.
+template <int L, bool GRAD>
+__device__ __forceinline__ float reward_fcc(const ocd_scenario_desc &d, const float (&w)[OCD_MAX_FEATURES],
+                                            float x, float y, float v, float sn, float cn,
+                                            const BumpGeom (&bg)[2], Q4 &q, const PkConsts &pkc)
+{
+    static_assert(L > 0, "lane-feature reward only");
+    const float tgt = d.target_speed;
+    const float bound = 4.0f * (tgt * tgt);
+    const float vel = v * sn;
+    const float dv = vel - tgt;
+    const float sq = dv * dv;
+    const bool pass0 = sq <= bound;
+    const float phi0 = min_tf(sq, bound);
+
+    float rl[L], pl[L];
+    float pmin = 0.0f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const float diff = x - d.lane_center[l];
+        rl[l] = diff * -1.0f;
+        const float d2 = rl[l] * rl[l];
+        pl[l] = d2 * 10.0f;
+        pmin = (l == 0) ? pl[0] : min_tf(pmin, pl[l]);
+    }
+    int ntie_min = 0;
+#pragma unroll
+    for (int l = 0; l < L; ++l) ntie_min += (pl[l] == pmin) ? 1 : 0;
+
+    // ---- bump_fwd of the four units: (car 0, car 1) pairs for x and for y ----
+    const v2f WX = {bg[0].wx, bg[1].wx}, WY = {bg[0].wy, bg[1].wy};
+    const v2f ZNX = div2_(v2f{x - bg[0].cx, x - bg[1].cx}, WX);
+    const v2f ZNY = div2_(v2f{y - bg[0].cy, y - bg[1].cy}, WY);
+    const bool cx0 = (ZNX.x * ZNX.x) < 1.0f, cx1 = (ZNX.y * ZNX.y) < 1.0f;
+    const bool cy0 = (ZNY.x * ZNY.x) < 1.0f, cy1 = (ZNY.y * ZNY.y) < 1.0f;
+    const v2f XCX = {cx0 ? ZNX.x : 0.0f, cx1 ? ZNX.y : 0.0f}, XCY = {cy0 ? ZNY.x : 0.0f, cy1 ? ZNY.y : 0.0f};
+    const v2f UBX = {1.0f - XCX.x * XCX.x, 1.0f - XCX.y * XCX.y}, UBY = {1.0f - XCY.x * XCY.x, 1.0f - XCY.y * XCY.y};
+    // ---- thr_fwd on the possibly-active side (see reward_state) ----
+    const bool side_p = x > d.fence_lo;
+    const float z = side_p ? x : -x;
+    const float xd = z - d.fence_lo;
+    const bool pos1 = xd > 0.0f;
+    const float uf1 = d.fence_shape * (pos1 ? xd : (0.0f + 0.01f));
+    const float xd2 = d.fence_width - xd;
+    const bool pos2 = xd2 > 0.0f;
+    const float uf2 = d.fence_shape * (pos2 ? xd2 : (0.0f + 0.01f));
+    const v2f UF = {uf1, uf2};
+    const v2f MBX = div2_(splat2(-1.0f), UBX), MBY = div2_(splat2(-1.0f), UBY), MF = div2_(splat2(-1.0f), UF);
+    const v2f EBX = exp_le1_2(MBX + splat2(1.0f), pkc), EBY = exp_le1_2(MBY + splat2(1.0f), pkc), EF = exp_le1_2(MF, pkc);
+    const float bxv0 = cx0 ? EBX.x : 0.0f, bxv1 = cx1 ? EBX.y : 0.0f;
+    const float byv0 = cy0 ? EBY.x : 0.0f, byv1 = cy1 ? EBY.y : 0.0f;
+    const float col0 = bxv0 * byv0, col1 = bxv1 * byv1;
+    const float pcol = max_tf(col0, col1);
+    const int ntie_col = ((col0 == pcol) ? 1 : 0) + ((col1 == pcol) ? 1 : 0);
+    const float F1 = pos1 ? EF.x : 0.0f, F2 = pos2 ? EF.y : 0.0f;
+    const float den = F1 + F2;
+    const float Ssum = F1 / den;
+    const float ax = (x < 0.0f) ? -x : x;
+    const float pf = Ssum * ax;
+
+    float r = w[0] * phi0;
+#pragma unroll
+    for (int l = 0; l < L; ++l) r = r + w[1 + l] * pl[l];
+    const float w_min = w[L + 1], w_col = w[L + 2], w_f = w[L + 3];
+    r = r + w_min * pmin;
+    r = r + w_col * pcol;
+    r = r + w_f * pf;
+    if (!GRAD) return r;
+
+    const float g_sq = pass0 ? w[0] : 0.0f;
+    const float g_dv = (g_sq * 2.0f) * dv;
+    q.qv = g_dv * sn;
+    const float g_sn = g_dv * v;
+    q.qth = g_sn * cn;
+
+    float qx = 0.0f, qy = 0.0f;
+    const float min_share = inv_count(ntie_min) * w_min;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        float gl = w[1 + l];
+        gl = (pl[l] == pmin) ? (gl + min_share) : gl;
+        const float g_d2 = gl * 10.0f;
+        const float g_r = (g_d2 * 2.0f) * rl[l];
+        qx = qx + g_r * -1.0f;
+    }
+    const float col_share = inv_count(ntie_col) * w_col;
+    const v2f SH = {(col0 == pcol) ? col_share : 0.0f, (col1 == pcol) ? col_share : 0.0f};
+    const float g_Ssum = w_f * ax;
+    const float g_ax = w_f * Ssum;
+    const v2f KBX = div2_(-MBX, UBX), KBY = div2_(-MBY, UBY), KF = div2_(-MF, UF);
+    // bump_bwd of the four units: ((share * other axis' bump) * e) * k, (-.) * 2, * xc
+    v2f GX, GY;
+    {
+        const v2f BX = {bxv0, bxv1}, BY = {byv0, byv1};
+        asm("v_pk_mul_f32 %[g], %[b], %[sh]\n"
+            "v_pk_mul_f32 %[g], %[g], %[e]\n"
+            "v_pk_mul_f32 %[g], %[g], %[k]\n"
+            "v_pk_mul_f32 %[g], %[g], 2.0 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]\n"
+            "v_pk_mul_f32 %[g], %[g], %[xc]\n"
+            : [g] "=&v"(GX) : [b] "v"(BY), [sh] "v"(SH), [e] "v"(EBX), [k] "v"(KBX), [xc] "v"(XCX));
+        asm("v_pk_mul_f32 %[g], %[b], %[sh]\n"
+            "v_pk_mul_f32 %[g], %[g], %[e]\n"
+            "v_pk_mul_f32 %[g], %[g], %[k]\n"
+            "v_pk_mul_f32 %[g], %[g], 2.0 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]\n"
+            "v_pk_mul_f32 %[g], %[g], %[xc]\n"
+            : [g] "=&v"(GY) : [b] "v"(BX), [sh] "v"(SH), [e] "v"(EBY), [k] "v"(KBY), [xc] "v"(XCY));
+    }
+    const v2f QBX = div2_(v2f{cx0 ? GX.x : 0.0f, cx1 ? GX.y : 0.0f}, WX);
+    const v2f QBY = div2_(v2f{cy0 ? GY.x : 0.0f, cy1 ? GY.y : 0.0f}, WY);
+    const v2f QF = div2_(v2f{g_Ssum, -Ssum}, v2f{den, den});
+    qx = qx + QBX.x; qy = qy + QBY.x;
+    qx = qx + QBX.y; qy = qy + QBY.y;
+    // thr_bwd
+    const float g_den = g_Ssum * QF.y;
+    FTape t1, t2;
+    t1.pos = pos1; t1.m = MF.x; t1.e = EF.x; t1.u = uf1;
+    t2.pos = pos2; t2.m = MF.y; t2.e = EF.y; t2.u = uf2;
+    const float ga = f_bwd_gated(QF.x, d.fence_shape, t1, KF.x);
+    const float gb = f_bwd_gated(g_den, d.fence_shape, t1, KF.x);
+    const float gc = f_bwd_gated(g_den, d.fence_shape, t2, KF.y);
+    const float g_z = (ga + gb) + (-gc);
+    qx = qx + (side_p ? g_z : -g_z);
+    const float sgn = (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f);
+    qx = qx + g_ax * sgn;
+    q.qx = qx; q.qy = qy;
+    return r;
+}
+
+// every feature of every lane: the packed evaluation where there is one (two scripted cars), else reward_state
+template <int NO, int L, bool GRAD>
+__device__ __forceinline__ float reward_every(const ocd_scenario_desc &d, const float (&w)[OCD_MAX_FEATURES],
+                                              float x, float y, float v, float sn, float cn,
+                                              const BumpGeom (&bg)[NO > 0 ? NO : 1], Q4 &q, const PkConsts &pkc)
+{
+#ifndef OCD_NO_PACKED
+    if constexpr (NO == 2 && L > 0) return reward_fcc<L, GRAD>(d, w, x, y, v, sn, cn, bg, q, pkc);
+    else
+#endif
+    return reward_state<NO, L, GRAD>(d, w, x, y, v, sn, cn, bg, q, nullptr, true, true);
+}
+
 // Lane-feature gradient factors of one trajectory (its weights are fixed for the whole episode): the chain
 //   g = w_l (+ w_min when lane l is the sole minimum) ; g_d2 = g * 10 ; (g_d2 * 2)
 // of the backward pass evaluated once, outside the SGD loop (same operations, same order, hoisted).

@@ -479,7 +479,7 @@ mpc_kernel(const KernelParams p)
                     // their collision box overlaps the fence region, a pass with a multi-feature lane is COMMON (most
                     // passes of the slowest wavefronts): decided before the evaluation, one evaluation per pass
                     if (__builtin_expect((multi_f | multi_c) != 0ull, 0)) {
-                        if (multi_c != 0ull) r = reward_state<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, true, true);
+                        if (multi_c != 0ull) r = reward_every<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, pkc);
                         else r = reward_fc<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, nc, q, pkc);
                         OCD_STAMP(5); OCD_STAMP_COUNT(12); // every feature / fence + one car per lane
                     } else {
@@ -493,7 +493,7 @@ mpc_kernel(const KernelParams p)
                     r = reward_one<NO, L, GRAD, false, phi0_in_chain>(d, w, xn, yn, vn, sn, cn, bg, nc, nf, true, true, q, pkc, lgc, feat_mask);
                     OCD_STAMP(6); OCD_STAMP_COUNT(13);     // one feature per lane
                     if (__builtin_expect((multi_f | multi_c) != 0ull, 0)) {
-                        if (multi_c != 0ull) r = reward_state<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, true, true);
+                        if (multi_c != 0ull) r = reward_every<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, pkc);
                         else r = reward_fc<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, nc, q, pkc);
                         OCD_STAMP(5); OCD_STAMP_COUNT(12); // every feature / fence + one car per lane
                     }

@@ -66,6 +66,24 @@ def main():
             row += f"{v:>12d}" + (f" ({v / npass:7.1f})" if i < 11 else " " * 10)
         print(row)
     print(f"{'total cycles (per pass)':<36}" + "".join(f"{int(tot[w]):>12d} ({tot[w] / npass:7.1f})" for _, w in picks))
+    hw = st[:, 14]
+    if (hw >> 40).all():                   # latency build of the chunked kernel: slot 14 = HW_ID | XCC_ID << 32
+        key = [((int(v) >> 32) & 0xf, (int(v) >> 13) & 7, (int(v) >> 12) & 1, (int(v) >> 8) & 0xf, (int(v) >> 4) & 3) for v in hw]
+        from collections import Counter
+        per_simd = Counter(key)
+        shared = [k for k, n in per_simd.items() if n > 1]
+        print(f"placement: {len(per_simd)} SIMDs used by {len(key)} wavefronts; SIMDs with more than one wavefront: {len(shared)}")
+        slow = order[-8:][::-1]
+        for wv in slow:
+            k = key[wv]
+            print(f"  wavefront {wv}: {int(tot[wv])} cycles, (xcc, se, sh, cu, simd) = {k}, wavefronts on that SIMD: {per_simd[k]}, "
+                  f"on that CU: {sum(n for kk, n in per_simd.items() if kk[:4] == k[:4])}")
+        per_cu = Counter(k[:4] for k in key)
+        print(f"  wavefronts per CU: min {min(per_cu.values())} max {max(per_cu.values())} over {len(per_cu)} CUs")
+        # mean total cycles of the wavefronts by how many share their SIMD
+        for n in sorted(set(per_simd.values())):
+            sel = [i for i, k in enumerate(key) if per_simd[k] == n]
+            print(f"  {len(sel)} wavefronts on SIMDs holding {n}: mean {tot[sel].mean():.0f} cycles, max {tot[sel].max():.0f}")
 
 
 if __name__ == "__main__":
