@@ -561,7 +561,7 @@ mpc_chunk_kernel(const KernelParams p)
     }
     if (p.mode == OCD_MODE_ROLLOUT && writer) p.returns_out[prob] = G_ret;
 #ifdef OCD_STAMPS
-    OCD_STAMP(0);
+    OCD_STAMP_LAST;
     if constexpr (LAT) {                                       // (slot 14 counts a path the latency build does not have)
         unsigned hw, xcc;                                      // where this wavefront ran: HW_ID | XCC_ID << 32
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));

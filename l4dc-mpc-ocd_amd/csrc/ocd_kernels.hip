@@ -764,7 +764,13 @@ mpc_kernel(const KernelParams p)
     }
     if (p.mode == OCD_MODE_ROLLOUT && writer) p.returns_out[prob] = G_ret;
 #ifdef OCD_STAMPS
-    OCD_STAMP(0);
+    OCD_STAMP_LAST;
+    if constexpr (LAT) {                                       // (slot 14 counts a path the latency builds do not have)
+        unsigned hw, xcc;                                      // where this wavefront ran: HW_ID | XCC_ID << 32
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        st_acc[14] = (unsigned long long)hw | ((unsigned long long)(xcc & 0xf) << 32) | (1ull << 40);
+    }
     if (p.debug && lane == 0)
         for (int i = 0; i < 16; ++i) p.debug[((size_t)blockIdx.x * (V == V_SEG ? 1 : K) + wave) * 16 + i] = st_acc[i];
 #endif

@@ -41,13 +41,22 @@ template <bool B> using bool_c = std::integral_constant<bool, B>;
 // wavefront (block, wave) go to p.debug[(block * K + wave) * 16 + section]; no output depends on them.
 #ifdef OCD_STAMPS
 #define OCD_STAMP_DECL unsigned long long st_acc[16] = {0}, st_last = __builtin_amdgcn_s_memtime();
-#define OCD_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long st_now = __builtin_amdgcn_s_memtime(); \
-                          __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); st_acc[i] += st_now - st_last; st_last = st_now; } while (0)
+#define OCD_STAMP_NOW(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long st_now = __builtin_amdgcn_s_memtime(); \
+                              __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); st_acc[i] += st_now - st_last; st_last = st_now; } while (0)
+#ifdef OCD_STAMPS_LIGHT
+// (make stamps_light: only the wavefront's total and its placement -- two s_memtime per wavefront, the product's speed)
+#define OCD_STAMP(i) do { } while (0)
+#define OCD_STAMP_COUNT(i) do { } while (0)
+#else
+#define OCD_STAMP(i) OCD_STAMP_NOW(i)
 #define OCD_STAMP_COUNT(i) do { st_acc[i] += 1; } while (0)
+#endif
+#define OCD_STAMP_LAST OCD_STAMP_NOW(0)
 #else
 #define OCD_STAMP_DECL
 #define OCD_STAMP(i) do { } while (0)
 #define OCD_STAMP_COUNT(i) do { } while (0)
+#define OCD_STAMP_LAST do { } while (0)
 #endif
 
 } // namespace ocd

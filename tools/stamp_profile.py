@@ -27,8 +27,9 @@ def main():
     ap.add_argument("--no-lat", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--pop", type=int, default=0, help="override the population (e.g. the share of one of 8 GPUs)")
+    ap.add_argument("--light", action="store_true", help="the build with two stamps per wavefront (make stamps_light): totals and placement only")
     a = ap.parse_args()
-    os.environ["OCD_HIP_LIB"] = os.path.join(ROOT, "l4dc-mpc-ocd_amd", "csrc", "libocd_hip_stamps.so")
+    os.environ["OCD_HIP_LIB"] = os.path.join(ROOT, "l4dc-mpc-ocd_amd", "csrc", "libocd_hip_stamps_light.so" if a.light else "libocd_hip_stamps.so")
     import torch
     from l4dc_mpc_ocd_amd import scenarios
     from l4dc_mpc_ocd_amd.engine import Engine
@@ -73,12 +74,27 @@ def main():
         per_simd = Counter(key)
         shared = [k for k, n in per_simd.items() if n > 1]
         print(f"placement: {len(per_simd)} SIMDs used by {len(key)} wavefronts; SIMDs with more than one wavefront: {len(shared)}")
+        pct = np.percentile(tot, [50, 90, 99, 99.9, 100])
+        print("  wavefront cycles: median / 90 % / 99 % / 99.9 % / max = " + " / ".join(f"{q:.0f}" for q in pct))
         slow = order[-8:][::-1]
         for wv in slow:
             k = key[wv]
             print(f"  wavefront {wv}: {int(tot[wv])} cycles, (xcc, se, sh, cu, simd) = {k}, wavefronts on that SIMD: {per_simd[k]}, "
                   f"on that CU: {sum(n for kk, n in per_simd.items() if kk[:4] == k[:4])}")
         per_cu = Counter(k[:4] for k in key)
+        cu_tot = {}
+        for i, k in enumerate(key):
+            cu_tot.setdefault(k[:4], []).append(float(tot[i]))
+        cu_mean = sorted(((np.mean(v), np.max(v) - np.min(v), k) for k, v in cu_tot.items()), reverse=True)
+        qs = np.percentile([m for m, _, _ in cu_mean], [0, 10, 50, 90, 99, 100])
+        print("  per-CU mean cycles: min / 10 % / median / 90 % / 99 % / max = " + " / ".join(f"{q:.0f}" for q in qs))
+        print("  slowest CUs (mean cycles, spread inside the CU, (xcc, se, sh, cu)): " +
+              "; ".join(f"{m:.0f} +-{sp:.0f} {k}" for m, sp, k in cu_mean[:6]))
+        sec = st[:, :11].astype(np.float64)
+        slow_cu = [i for i, k in enumerate(key) if k[:4] in {c for _, _, c in cu_mean[:8]}]
+        rest = [i for i in range(len(key)) if i not in set(slow_cu)]
+        ratio = sec[slow_cu].mean(0) / np.maximum(sec[rest].mean(0), 1.0)
+        print("  section time on the 8 slowest CUs / on the others: " + " ".join(f"{r:.2f}" for r in ratio))
         print(f"  wavefronts per CU: min {min(per_cu.values())} max {max(per_cu.values())} over {len(per_cu)} CUs")
         # mean total cycles of the wavefronts by how many share their SIMD
         for n in sorted(set(per_simd.values())):
