@@ -112,6 +112,10 @@ def test_argument_checks_precede_any_device_work():
     for knob in (b"no_latency_build", b"no_feature_skips", b"no_unified_features", b"chunk_size"):
         assert lib.ocd_scenario_set_option(h, knob, 1 if knob != b"chunk_size" else 5) == abi.OCD_OK
         assert lib.ocd_scenario_set_option(h, knob, 0) == abi.OCD_OK
+    info = (C.c_int32 * 8)(*([7] * 8))
+    assert lib.ocd_scenario_last_launch(h, info) == abi.OCD_OK and list(info) == [0] * 8     # nothing launched yet
+    assert lib.ocd_scenario_last_launch(None, info) == abi.OCD_ERR_INVALID_ARG
+    assert lib.ocd_scenario_last_launch(h, None) == abi.OCD_ERR_INVALID_ARG
     assert lib.ocd_mpc_reward_batch(h, p, p, 0, None, None, p, p, None, 1, None) == abi.OCD_ERR_INVALID_ARG  # controls NULL
     # terminal-value table: argument checks run on the host
     g = np.array([0.0, 1.0, 2.0], dtype=np.float32)

@@ -50,6 +50,9 @@ def main():
         mode = int(rng.choice([0, 2, 3, 4]))
         eng.set_option("scan_mode", mode)
         eng.set_option("no_latency_build", int(rng.integers(0, 2)))
+        # every compiled chunk size of the shape in turn (sizes that do not divide H included); 0 = the launcher's choice
+        chunk = int(rng.choice({10: [0, 2, 5], 15: [0, 2, 3, 5], 25: [0, 3, 5]}.get(H, [0]))) if mode == 4 else 0
+        eng.set_option("chunk_size", chunk)
         B = int(rng.integers(1, 40))
         ws = np.zeros((B, NO + 1, 4), dtype=np.float32)
         ws[:, 0, 0] = rng.uniform(-0.2, 0.2, B); ws[:, 0, 1] = rng.uniform(-1.4, -0.5, B)
@@ -72,7 +75,7 @@ def main():
         ok = ok and all(same(ro[k], rr[k]) for k in ("ctrl", "traj", "returns"))
         if not ok:
             bad += 1
-            print(f"MISMATCH case {case}: H={H} NO={NO} L={L} kind={kind} scan_mode={mode} B={B}", flush=True)
+            print(f"MISMATCH case {case}: H={H} NO={NO} L={L} kind={kind} scan_mode={mode} chunk={chunk} B={B}", flush=True)
         if case % 25 == 24:
             print(f"{case + 1} cases, {bad} mismatches", flush=True)
     print(f"done: {a.cases} cases, {bad} mismatches")

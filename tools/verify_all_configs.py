@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--configs", default="2,3,4,5")
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--scan-mode", type=int, default=0, help="force a kernel variant (ocd_scenario_set_option scan_mode)")
+    ap.add_argument("--split", type=int, default=8, help="also run every config as this many equal episode blocks (the "
+                    "per-GPU shares of a strong split: other launch shapes, other kernel builds); 0 = whole batch only")
     a = ap.parse_args()
     import oracle_lib
     from l4dc_mpc_ocd_amd import scenarios
@@ -32,6 +34,8 @@ def main():
         eng = Engine(scn, "cuda:0")
         eng.set_option("scan_mode", a.scan_mode)
         got = eng.rollout(inits, w32)["returns"]
+        ll = eng.last_launch()
+        whole_tag = f"{ll['mapping']}" + (f" S={ll['chunk']}" if ll["chunk"] else "") + f" x{ll['trajectories_per_wavefront']} build={ll['build_wavefronts_per_simd']}"
         t1 = time.perf_counter()
         ref = np.empty_like(got)
         E = got.size
@@ -43,10 +47,22 @@ def main():
         t2 = time.perf_counter()
         same = (got == ref) | (np.isnan(got) & np.isnan(ref))
         nonfinite = int((~np.isfinite(ref)).sum())
-        print(f"cfg{cfg} {scn.name} H={scn.desc.horizon}: {E} episodes, identical {int(same.sum())}/{E} "
+        print(f"cfg{cfg} {scn.name} H={scn.desc.horizon} [{whole_tag}]: {E} episodes, identical {int(same.sum())}/{E} "
               f"(non-finite returns: {nonfinite}); GPU {t1 - t0:.2f} s incl. setup, oracle {t2 - t1:.1f} s on {a.threads} threads",
               flush=True)
         ok &= bool(same.all())
+        if a.split > 1 and E % a.split == 0:
+            blk = E // a.split
+            parts, tags = [], set()
+            for r in range(a.split):
+                parts.append(eng.rollout(inits, w32, ep_begin=r * blk, ep_end=(r + 1) * blk)["returns"])
+                ll = eng.last_launch()
+                tags.add(f"{ll['mapping']}" + (f" S={ll['chunk']}" if ll["chunk"] else "") + f" x{ll['trajectories_per_wavefront']}"
+                         f" build={ll['build_wavefronts_per_simd']}")
+            got2 = np.concatenate(parts)
+            same2 = (got2 == ref) | (np.isnan(got2) & np.isnan(ref))
+            print(f"cfg{cfg} as {a.split} blocks of {blk} episodes [{'; '.join(sorted(tags))}]: identical {int(same2.sum())}/{E}", flush=True)
+            ok &= bool(same2.all())
     sys.exit(0 if ok else 1)
 
 
