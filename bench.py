@@ -273,7 +273,7 @@ def main():
             dt = float(tt.item())
         # dominant kernel: average launch duration from HIP events on the launch stream
         kern_ms = eng.time_rollout(init_dev, w_dev, e0, e1, ret_dev, reps=max(3, min(steps, 20)))
-        return dt, kern_ms, fit, (cfg, scn, inits, w32, P, N, S, e1 - e0)
+        return dt, kern_ms, fit, (cfg, scn, inits, w32, P, N, S, e1 - e0, eng.last_launch())
 
     def share_block(cfg_index, r, w, steps, warmup):
         """Rank r's block of a w-way strong split of BASELINE config cfg_index, on this GPU alone."""
@@ -285,7 +285,12 @@ def main():
         return b
 
     def block(cfg_index, dt, kern_ms, ctx, steps, per_gpu_only=False):
-        cfg, scn, inits, w32, P, N, S, n_local = ctx
+        cfg, scn, inits, w32, P, N, S, n_local, launch = ctx
+        kernel_name = ("ocd::mpc_chunk_kernel" if launch["scan_mode"] == 4 else "ocd::mpc_kernel") + \
+            f" ({launch['mapping']}" + (f", {launch['chunk']} steps per lane" if launch["chunk"] else "") + \
+            f", {launch['trajectories_per_wavefront']} trajectories per wavefront, {launch['workgroups']} workgroups x " \
+            f"{launch['wavefronts_per_workgroup']} wavefronts" + \
+            (", latency build" if launch["build_wavefronts_per_simd"] == 1 else "") + ")"
         n_done = n_local if per_gpu_only else P * N * S           # episodes this timing covers per step
         d = scn.desc
         nbytes, flops = algorithmic_per_episode(d)
@@ -317,7 +322,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": PMC_SOURCE if pmc else None,
-                         "kernel": "ocd::mpc_kernel / ocd::mpc_chunk_kernel", "kernel_ms": kern_ms,
+                         "kernel": kernel_name, "kernel_ms": kern_ms, "launch": launch,
                          "algorithmic_bytes_per_episode": nbytes,
                          "note": "path is fp32-VALU issue bound, not HBM bound (SURVEY.md 8d); see valu"},
             "valu": valu,
@@ -376,7 +381,7 @@ def main():
                                                    "installed"}
 
     if rank == 0:
-        cfg, scn, inits, w32, P, N, S, n_local = ctx
+        cfg, scn, inits, w32, P, N, S, n_local, _ = ctx
         d = scn.desc
         hb = block(args.config, dt, kern_ms, ctx, args.steps, per_gpu_only=bool(emulate))
         out = {

@@ -987,12 +987,10 @@ static hipError_t launch_mpc(const KernelParams &p_in, hipStream_t st)
     else if (p.scan_mode == 0) {
         const long long waves_seg = seg_cap ? ceil_div(n, seg_cap) : 0;
         const long long waves_lds = ceil_div(n, G.SEGS) * K;
-        const long long waves_chunk = chunk ? ceil_div(n, 64 / (K * ceil_div(H, chunk))) : 0;
         // (round-3 sweeps, tools/sweep_sizes.sh: once the one-lane-per-step mappings need a second wavefront on a SIMD,
         //  the chunked mapping with the smallest chunk that still fits one wavefront per SIMD is ahead at every horizon;
         //  the one exception found, 6 144 trajectories at H = 10 where V_LDS is 7 % faster, is not worth a rule)
         const bool chunk_wins = chunk && waves_lds > simds;
-        (void)waves_chunk;
         if (row_cap && n * K <= simds) variant = V_ROW;
         else if (seg_cap && waves_seg <= simds) variant = V_SEG;
         else if (chunk_wins) variant = V_CHUNK;
