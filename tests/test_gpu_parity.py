@@ -220,13 +220,16 @@ def test_all_scan_variants_bitwise(oracle, eng_factory, hip, scan_mode, name, H,
                                           ("local_opt", 15, 3), ("local_opt", 15, 5), ("replanning", 15, 2),
                                           ("replanning", 15, 3), ("replanning", 10, 2), ("replanning", 10, 5),
                                           ("merging", 25, 3), ("merging", 25, 5), ("local_opt", 25, 3),
-                                          ("merging", 10, 2)])
+                                          ("merging", 10, 2), ("finite_horizon+", 10, 2), ("local_opt+", 15, 2),
+                                          ("local_opt+", 15, 3), ("finite_horizon+", 25, 3), ("local_opt+", 25, 5)])
 def test_chunk_sizes_bitwise(oracle, eng_factory, hip, name, H, chunk):
     """V_CHUNK with every compiled chunk size S, including sizes that do not divide the horizon (the last lane of a
     segment then owns H - (NC-1)*S steps and padding): latency build, throughput build (no_latency_build), the
     three-wavefront build (a launch of >= 3 wavefronts per SIMD is too big for a test; its code differs only in
-    register allocation), full and partial packing, an overflowing problem among the others."""
-    scn = scenarios.SCENARIOS[name](horizon=H, n_iter=18)
+    register allocation), full and partial packing, an overflowing problem among the others.  "+" = extra_inits
+    (six control initialisations per trajectory: naive_planner.py:112-116)."""
+    extra = name.endswith("+")
+    scn = scenarios.SCENARIOS[name.rstrip("+")](horizon=H, n_iter=18, **({"extra_inits": True} if extra else {}))
     eng = eng_factory(scn)
     B = 23
     ws = _world_states(scn, B, seed=H + chunk)
@@ -245,7 +248,9 @@ def test_chunk_sizes_bitwise(oracle, eng_factory, hip, name, H, chunk):
             outs.append(eng.plan_batch(ws, w, want_all=True))
             ll = eng.last_launch()
             assert (ll["scan_mode"], ll["chunk"], ll["specialised_horizon"]) == (4, chunk, H), ll
-            assert ll["build_wavefronts_per_simd"] == (0 if nolat else 1) and (segs == 0 or ll["trajectories_per_wavefront"] == segs)
+            cap = 64 // (scn.desc.n_ctrl_inits * -(-H // chunk))
+            assert ll["build_wavefronts_per_simd"] == (0 if nolat else 1)
+            assert segs == 0 or ll["trajectories_per_wavefront"] == min(segs, cap)
             ro = eng.rollout(inits, w[:2], want_traj=True)
             assert_bitwise(ro["ctrl"], rr["ctrl"], "controls"); assert_bitwise(ro["traj"], rr["traj"], "traj")
             assert_bitwise(ro["returns"], rr["returns"], "returns")
