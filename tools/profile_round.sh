@@ -6,7 +6,7 @@
 # A workload token is a BASELINE config index, or <index>s = the share of rank 0 of an 8-way strong split of that
 # config run on this one GPU (bench.py --emulate-rank 0/8): 4s = 2 048 episodes at H=15, 5s = 4 096 at H=25.
 # Writes rocpd databases under gpurun_out/prof_<round>/ (scratch) and the condensed summaries
-# profiles/<round>_cfg<N>_rocprofv3.txt + profiles/pmc_counters.json (tracked).
+# profiles/<round>_cfg<N>[_share8]_rocprofv3.txt + profiles/pmc_counters.json (tracked).
 set -e -o pipefail
 ROUND=${1:-r02}
 CONFIGS=${2:-"2 3 4 5"}
@@ -18,7 +18,7 @@ SQ="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_
 for c in $CONFIGS; do
     n=${c%s}
     steps=30; [ "$n" -ge 4 ] && steps=6
-    extra=""; [ "$c" != "$n" ] && { extra="--emulate-rank 0/8"; steps=20; }
+    extra=""; tag=$n; [ "$c" != "$n" ] && { extra="--emulate-rank 0/8"; steps=20; tag="${n}_share8"; }
     args="bench.py --config $n $extra --steps $steps --warmup 2 --no-extras --no-cpu-baseline"
     cd /tmp
     rocprofv3 --kernel-trace --stats -d "$OUT/c${c}_stats" -o res -- python3 "$ROOT"/$args > "$OUT/c${c}_stats.log" 2>&1
@@ -27,7 +27,7 @@ for c in $CONFIGS; do
     rocprofv3 --pmc $SQ --kernel-trace -d "$OUT/c${c}_sq" -o res -- python3 "$ROOT"/$args > "$OUT/c${c}_sq.log" 2>&1
     cd "$ROOT"
     python3 tools/rocprof_summary.py $(find "$OUT/c${c}_stats" "$OUT/c${c}_fetch" "$OUT/c${c}_write" "$OUT/c${c}_sq" -name "*.db" | sort) \
-        > "$OUT/${ROUND}_cfg${c}_rocprofv3.txt"
+        > "$OUT/${ROUND}_cfg${tag}_rocprofv3.txt"
     echo "workload $c profiled"
 done
 python3 tools/rocprof_summary.py --json "$ROUND" "$OUT" > "$OUT/pmc_counters.json"
