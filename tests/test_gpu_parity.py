@@ -183,7 +183,7 @@ def test_rollout_bitwise(oracle, eng_factory, name, H, P, N):
                                            ("merging", 25, 12), ("local_opt", 25, 12)])
 def test_all_scan_variants_bitwise(oracle, eng_factory, hip, scan_mode, name, H, n_iter):
     """scan_mode 1 (LDS windows), 2 (DPP row shifts, H <= 16), 3 (all K initialisations in one
-    wavefront, K*H <= 64) and 4 (a lane owns a chunk of 5 steps) are four implementations of the same
+    wavefront, K*H <= 64) and 4 (a lane owns a chunk of consecutive steps) are four implementations of the same
     recurrences; all must reproduce the oracle bit for bit, plans, losses and episodes.  (A shape without
     the requested kernel runs the LDS kernel.)"""
     scn = scenarios.SCENARIOS[name](horizon=H, n_iter=n_iter)
