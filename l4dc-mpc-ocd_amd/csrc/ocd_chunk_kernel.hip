@@ -1,10 +1,11 @@
-// ocd_chunk_kernel.hip -- the planner kernel for long horizons at throughput (V_CHUNK), gfx950.
+// ocd_chunk_kernel.hip -- the planner kernel for batches beyond one lane-per-step wavefront per SIMD (V_CHUNK), gfx950.
 //
 // Same algorithm, arithmetic contract and entry points as ocd::mpc_kernel (ocd_kernels.hip; reference:
 // naive_planner.py:33-77,81-164, simulation_utils.py:9-21, merging.py:32-83, mpc_ord.py:67-106); what
 // changes is the mapping.  With one lane per horizon step every lane runs all H-1 rounds of the four
 // horizon recurrences -- O(H^2) lane-work, two thirds of the kernel time at H = 25.  Here a lane owns a
-// CHUNK of S consecutive steps, NC = H/S lanes per (trajectory, control initialisation) pair:
+// CHUNK of S consecutive steps, NC = ceil(H/S) lanes per (trajectory, control initialisation) pair (S need not divide
+// H: the last lane of a segment then owns fewer steps and padding, see SL below):
 //
 //   * the recurrences run NC-1 rounds, each walking the lane's S steps sequentially and handing the
 //     chunk's end value to the neighbouring lane (wave_shr:1 / wave_shl:1 + a select at the segment
@@ -33,13 +34,14 @@ namespace ocd {
 
 // LAT: the launch puts at most one wavefront on a SIMD (the per-GPU shares of BASELINE configs 4 / 5: 1 024
 //   wavefronts), so it lasts as long as its slowest wavefront and nothing hides that wavefront's branches and its
-//   ballot -> SALU -> branch stalls (ocd_kernels.hip, LAT).  This build evaluates reward_one unconditionally and
-//   straight-line for every step of the chunk and repairs the rare step with a multi-feature lane out of line.
+//   ballot -> SALU -> branch stalls (ocd_kernels.hip, LAT).  Per step ONE test chooses between one feature per lane
+//   (reward_one, straight line, no sub-skips) and the multi-feature evaluations (reward_fc / reward_every); the build
+//   also claims its SIMD (see the a255 clobber below).
 //   The diagnostics knobs no_feature_skips / no_unified_features select the LAT = false build.
 // OCC3: compiled for THREE wavefronts per SIMD (<= 168 VGPRs; hipcc spills 20-70 dwords of the per-step tape to
-//   scratch, which three wavefronts hide): launches with at least three full-packed wavefronts per SIMD gain 4-5 %
-//   (config 4 whole 19.6 -> 18.7 ms, config 5 whole 41.0 -> 39.3 ms, 16 x config 3 16.9 -> 16.0 ms); smaller launches
-//   lose 3-4 % and keep the two-wavefront build.  Same code, same results.
+//   scratch, which three wavefronts hide) -- FOUR (128 VGPRs) for S <= 2: launches with at least three full-packed
+//   wavefronts per SIMD gain 4-5 % (config 4 whole 19.6 -> 18.7 ms, config 5 whole 41.0 -> 39.3 ms); smaller launches
+//   lose 3-4 % and keep the unconstrained build.  Same code, same results.
 template <int HT, int NO, int L, int S, bool LAT = false, bool OCC3 = false>
 __global__ void __launch_bounds__(64, OCC3 ? (S <= 2 ? 4 : 3) : 1) OCD_CHUNK_OCC
 mpc_chunk_kernel(const KernelParams p)
