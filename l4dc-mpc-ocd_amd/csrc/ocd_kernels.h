@@ -108,9 +108,9 @@ static inline void note_launch(const KernelParams &p, int mode, int chunk, int s
 // divide H (the last lane of a segment then owns fewer steps).  Small S: more wavefronts of fewer instructions each --
 // the best size is the smallest one whose wavefronts still fit one per SIMD (launch_chunk_dispatch picks by cost).
 #define OCD_CHUNK_TABLE(X)                                                                    \
-    X(10, 1, 3, 2) X(10, 1, 3, 5) X(15, 1, 3, 2) X(15, 1, 3, 3) X(15, 1, 3, 5) X(25, 1, 3, 3) X(25, 1, 3, 5) \
+    X(10, 1, 3, 2) X(10, 1, 3, 5) X(15, 1, 3, 2) X(15, 1, 3, 3) X(15, 1, 3, 5) X(25, 1, 3, 2) X(25, 1, 3, 3) X(25, 1, 3, 5) \
     X(10, 2, 2, 2) X(10, 2, 2, 5) X(15, 2, 2, 2) X(15, 2, 2, 3) X(15, 2, 2, 5)                \
-    X(10, 2, 3, 2) X(10, 2, 3, 5) X(25, 2, 3, 3) X(25, 2, 3, 5)
+    X(10, 2, 3, 2) X(10, 2, 3, 5) X(25, 2, 3, 2) X(25, 2, 3, 3) X(25, 2, 3, 5)
 
 // (H, NO, L) with V_ROW / V_SEG LAT builds that carry the terminal value: the reference's own horizons on the shape
 // its value grids are made for (coarse_value_iteration.py: the three-lane finite-horizon world)

@@ -948,7 +948,8 @@ static int clampi(long long v, long long lo, long long hi) { return (int)(v < lo
 //     feature skips alone; K wavefronts meet once per control step);
 //   * V_SEG (single-wavefront workgroups spread evenly over the SIMDs, no workgroup barrier) while it gives
 //     at most one wavefront per SIMD, or up to four when it packs lanes as densely as V_LDS (K*H close to 64);
-//   * V_CHUNK (where compiled) as soon as V_LDS would need more than one wavefront per SIMD: a lane owns S steps,
+//   * V_CHUNK (where compiled) as soon as V_LDS would need more than one wavefront per SIMD, and at every size where
+//     neither V_ROW nor V_SEG exists (long horizons): a lane owns S steps,
 //     the wavefront S times the trajectories; launch_chunk_dispatch picks S by cost -- in effect the smallest compiled S
 //     whose wavefronts fit one per SIMD, then the one with the least work on the busiest SIMD;
 //   * else V_LDS, densest packing at one lane per step, LDS latency hidden by the other wavefronts.
@@ -990,7 +991,9 @@ static hipError_t launch_mpc(const KernelParams &p_in, hipStream_t st)
         // (round-3 sweeps, tools/sweep_sizes.sh: once the one-lane-per-step mappings need a second wavefront on a SIMD,
         //  the chunked mapping with the smallest chunk that still fits one wavefront per SIMD is ahead at every horizon;
         //  the one exception found, 6 144 trajectories at H = 10 where V_LDS is 7 % faster, is not worth a rule)
-        const bool chunk_wins = chunk && waves_lds > simds;
+        //  At horizons with neither DPP mapping (H > 16 and K*H > 64) the chunked kernel is ahead of V_LDS at every size
+        //  (H = 25, 128 ... 1 024 trajectories: 3.84-4.06 ms with S = 2 against 4.52-4.94).
+        const bool chunk_wins = chunk && (waves_lds > simds || (!row_cap && !seg_cap));
         if (row_cap && n * K <= simds) variant = V_ROW;
         else if (seg_cap && waves_seg <= simds) variant = V_SEG;
         else if (chunk_wins) variant = V_CHUNK;

@@ -219,7 +219,7 @@ def test_all_scan_variants_bitwise(oracle, eng_factory, hip, scan_mode, name, H,
 @pytest.mark.parametrize("name,H,chunk", [("finite_horizon", 10, 2), ("finite_horizon", 10, 5), ("local_opt", 15, 2),
                                           ("local_opt", 15, 3), ("local_opt", 15, 5), ("replanning", 15, 2),
                                           ("replanning", 15, 3), ("replanning", 10, 2), ("replanning", 10, 5),
-                                          ("merging", 25, 3), ("merging", 25, 5), ("local_opt", 25, 3),
+                                          ("merging", 25, 2), ("merging", 25, 3), ("merging", 25, 5), ("local_opt", 25, 2), ("local_opt", 25, 3),
                                           ("merging", 10, 2), ("finite_horizon+", 10, 2), ("local_opt+", 15, 2),
                                           ("local_opt+", 15, 3), ("finite_horizon+", 25, 3), ("local_opt+", 25, 5)])
 def test_chunk_sizes_bitwise(oracle, eng_factory, hip, name, H, chunk):

@@ -51,7 +51,7 @@ def main():
         eng.set_option("scan_mode", mode)
         eng.set_option("no_latency_build", int(rng.integers(0, 2)))
         # every compiled chunk size of the shape in turn (sizes that do not divide H included); 0 = the launcher's choice
-        chunk = int(rng.choice({10: [0, 2, 5], 15: [0, 2, 3, 5], 25: [0, 3, 5]}.get(H, [0]))) if mode == 4 else 0
+        chunk = int(rng.choice({10: [0, 2, 5], 15: [0, 2, 3, 5], 25: [0, 2, 3, 5]}.get(H, [0]))) if mode == 4 else 0
         eng.set_option("chunk_size", chunk)
         B = int(rng.integers(1, 40))
         ws = np.zeros((B, NO + 1, 4), dtype=np.float32)

@@ -10,7 +10,7 @@ for pop in 8 16 24 32 48 64 128; do
     python tools/sweep.py --configs 4 --pop $pop --scan-mode 0,1,2,3 --reps 3
     for ch in 2 3 5; do python tools/sweep.py --configs 4 --pop $pop --scan-mode 4 --chunk $ch --reps 3; done
 done
-for pop in 8 16 32 64 128 256; do
+for pop in 1 4 8 16 32 64 128 256; do
     python tools/sweep.py --configs 5 --pop $pop --scan-mode 0,1 --reps 3
-    python tools/sweep.py --configs 5 --pop $pop --scan-mode 4 --chunk 5 --reps 3
+    for ch in 2 3 5; do python tools/sweep.py --configs 5 --pop $pop --scan-mode 4 --chunk $ch --reps 3; done
 done
