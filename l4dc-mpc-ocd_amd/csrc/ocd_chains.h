@@ -65,7 +65,7 @@ __device__ __forceinline__ void row_fwd_vth(float &v, float &th, float a_c, floa
                      "v_mov_b32_dpp %[th], %[thn]" OCD_ROW_SHR                                            \
                      "v_add_f32 %[thn], %[th], %[wdt]\n"                                                  \
                      "v_mov_b32_dpp %[v], %[t]" OCD_ROW_SHR)                                              \
-                 : [v] "+v"(v), [th] "+v"(th), [thn] "+v"(thn), [t] "=&v"(tmp)                           \
+                 : [v] "+&v"(v), [th] "+&v"(th), [thn] "+&v"(thn), [t] "=&v"(tmp)                           \
                  : [ac] "v"(a_c), [wdt] "v"(wdt), [fr] "s"(fr), [dt] "s"(dt));
     OCD_CHAIN_ROUNDS(HT, OCD_STMT);
 #undef OCD_STMT
@@ -86,7 +86,7 @@ __device__ __forceinline__ void seg_fwd_vth(float &v, float &th, float ev, float
                      "v_cndmask_b32_dpp %[th], %[thn], %[eth], vcc" OCD_WAVE_SHR                          \
                      "v_add_f32 %[thn], %[th], %[wdt]\n"                                                  \
                      "v_cndmask_b32_dpp %[v], %[t], %[ev], vcc" OCD_WAVE_SHR)                             \
-                 : [v] "+v"(v), [th] "+v"(th), [thn] "+v"(thn), [t] "=&v"(tmp)                           \
+                 : [v] "+&v"(v), [th] "+&v"(th), [thn] "+&v"(thn), [t] "=&v"(tmp)                           \
                  : [ac] "v"(a_c), [wdt] "v"(wdt), [ev] "v"(ev), [eth] "v"(eth), [fr] "s"(fr), [dt] "s"(dt), \
                    [m] "s"(first_mask)                                                                    \
                  : "vcc");
@@ -105,7 +105,7 @@ __device__ __forceinline__ void row_fwd_xy(float &x, float &y, float cdb, float 
                  REP("v_add_f32_dpp %[x], %[x], %[cdb]" OCD_ROW_SHR                                       \
                      "v_add_f32_dpp %[y], %[y], %[sdb]" OCD_ROW_SHR                                       \
                      "s_nop 0\n")                                                                         \
-                 : [x] "+v"(x), [y] "+v"(y) : [cdb] "v"(cdb), [sdb] "v"(sdb));
+                 : [x] "+&v"(x), [y] "+&v"(y) : [cdb] "v"(cdb), [sdb] "v"(sdb));
     OCD_CHAIN_ROUNDS(HT, OCD_STMT);
 #undef OCD_STMT
 }
@@ -130,7 +130,7 @@ __device__ __forceinline__ void row_fwd_xy_phi0_h10(float &x, float &y, float cd
                  OCD_XY("v_mul_f32 %[qv], %[g], %[sn]\n")
                  OCD_XY("v_mul_f32 %[g], %[g], %[vn]\n")
                  "v_mul_f32 %[qth], %[g], %[cn]\n"
-                 : [x] "+v"(x), [y] "+v"(y), [t] "=&v"(t), [g] "=&v"(g), [qv] "=&v"(qv), [qth] "=&v"(qth)
+                 : [x] "+&v"(x), [y] "+&v"(y), [t] "=&v"(t), [g] "=&v"(g), [qv] "=&v"(qv), [qth] "=&v"(qth)
                  : [cdb] "v"(cdb), [sdb] "v"(sdb), [vn] "v"(vn), [sn] "v"(sn), [cn] "v"(cn), [tgt] "v"(tgt),
                    [bound] "v"(bound), [w0] "v"(w0)
                  : "vcc");
@@ -149,7 +149,7 @@ __device__ __forceinline__ void seg_fwd_xy(float &x, float &y, float ex, float e
                      "v_cndmask_b32_dpp %[y], %[sy], %[ey], vcc" OCD_WAVE_SHR                             \
                      "v_add_f32 %[sy], %[y], %[sd]\n"                                                     \
                      "v_cndmask_b32_dpp %[x], %[sx], %[ex], vcc" OCD_WAVE_SHR)                            \
-                 : [x] "+v"(x), [y] "+v"(y), [sx] "=&v"(sx), [sy] "+v"(sy)                               \
+                 : [x] "+&v"(x), [y] "+&v"(y), [sx] "=&v"(sx), [sy] "+&v"(sy)                               \
                  : [cd] "v"(cd), [sd] "v"(sd), [ex] "v"(ex), [ey] "v"(ey), [m] "s"(first_mask)           \
                  : "vcc");
     OCD_CHAIN_ROUNDS(HT, OCD_STMT);
@@ -174,7 +174,7 @@ __device__ __forceinline__ void seg_bwd_xy(float &Lx, float &Ly, float qx, float
                      "v_cndmask_b32_dpp %[Ly], %[ay], %[z], vcc" OCD_WAVE_SHL                             \
                      "v_add_f32 %[ay], %[qy], %[Ly]\n"                                                    \
                      "v_cndmask_b32_dpp %[Lx], %[ax], %[z], vcc" OCD_WAVE_SHL)                            \
-                 : [Lx] "+v"(Lx), [Ly] "+v"(Ly), [ax] "=&v"(ax), [ay] "+v"(ay)                           \
+                 : [Lx] "+&v"(Lx), [Ly] "+&v"(Ly), [ax] "=&v"(ax), [ay] "+&v"(ay)                           \
                  : [qx] "v"(qx), [qy] "v"(qy), [z] "v"(zero), [m] "s"(last_mask)                         \
                  : "vcc");
     OCD_CHAIN_ROUNDS(HT, OCD_STMT);
@@ -205,7 +205,7 @@ __device__ __forceinline__ void seg_bwd_vth(float &Lv, float &Lth, float qv, flo
                      "v_add_f32 %[ltd], %[qth], %[Lth]\n"                                                 \
                      "v_add_f32 %[ltd], %[ltd], %[tau]\n"                                                 \
                      "v_cndmask_b32_dpp %[Lv], %[s], %[z], vcc" OCD_WAVE_SHL)                             \
-                 : [Lv] "+v"(Lv), [Lth] "+v"(Lth), [ltd] "+v"(ltd), [av] "=&v"(av), [s] "=&v"(s), [g] "=&v"(g) \
+                 : [Lv] "+&v"(Lv), [Lth] "+&v"(Lth), [ltd] "+&v"(ltd), [av] "=&v"(av), [s] "=&v"(s), [g] "=&v"(g) \
                  : [qv] "v"(qv), [qth] "v"(qth), [gA1] "v"(gA1), [gv1] "v"(gv1), [v] "v"(v), [tau] "v"(tau), \
                    [z] "v"(zero), [fr] "s"(fr), [dt] "s"(dt), [m] "s"(last_mask)                          \
                  : "vcc");

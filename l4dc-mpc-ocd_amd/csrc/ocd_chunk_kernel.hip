@@ -22,6 +22,7 @@
 #include <stdint.h>
 
 #include "../../include/ocd.h"
+#include "ocd_chunk_chains.h"
 #include "ocd_device.h"
 #include "ocd_kernels.h"
 #include "ocd_lane.h"
@@ -70,7 +71,13 @@ mpc_chunk_kernel(const KernelParams p)
     const bool live = (slot < p.segs_used) && (prob_raw < p.n_problems);
     const long long prob = live ? prob_raw : (p.n_problems - 1);   // parked lanes shadow a real problem
     const unsigned long long live_mask = __ballot(live);
-    const unsigned long long real_mask = live_mask & ~__ballot(last);   // the lanes whose padding steps (if any) count
+    const unsigned long long last_mask = __ballot(last), first_mask = __ballot(first);
+    const unsigned long long real_mask = live_mask & ~last_mask;        // the lanes whose padding steps (if any) count
+#ifdef OCD_NO_ASM_CHAINS
+    constexpr bool asm_chains = false;
+#else
+    constexpr bool asm_chains = chunk_chain_supported<S, NC - 1>::value;   // hand-scheduled rounds (ocd_chunk_chains.h)
+#endif
 
     const float dt = d.dt, dt2 = d.dt_sq, fr = d.ego_friction, lr = d.learning_rate;
 
@@ -240,17 +247,21 @@ mpc_chunk_kernel(const KernelParams p)
             }
             // speed / heading at the start of the chunk: NC-1 rounds of "walk my S steps, hand the end to the lane above"
             float vs = ev, ths = eth;
+            if constexpr (asm_chains) {
+                chunk_fwd_vth<S, NC - 1>(vs, ths, ev, eth, a_c, wdt, fr, dt, first_mask);
+            } else {
 #pragma unroll
-            for (int r = 0; r < NC - 1; ++r) {
-                float v = vs, th = ths;
+                for (int r = 0; r < NC - 1; ++r) {
+                    float v = vs, th = ths;
 #pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    v = v + (a_c[s] - fr * (v * v)) * dt;
-                    th = th + wdt[s];
+                    for (int s = 0; s < S; ++s) {
+                        v = v + (a_c[s] - fr * (v * v)) * dt;
+                        th = th + wdt[s];
+                    }
+                    const float vb = wave_below(v), tb = wave_below(th);
+                    vs = first ? ev : vb;
+                    ths = first ? eth : tb;
                 }
-                const float vb = wave_below(v), tb = wave_below(th);
-                vs = first ? ev : vb;
-                ths = first ? eth : tb;
             }
             OCD_STAMP(1);                                  // clip, speed / heading recurrence
             // the lane's own S steps
@@ -296,14 +307,18 @@ mpc_chunk_kernel(const KernelParams p)
             OCD_STAMP(2);                                  // own steps, sincos
             // position at the start of the chunk
             float xs = ex, ys = ey;
+            if constexpr (asm_chains) {
+                chunk_fwd_xy<S, NC - 1>(xs, ys, ex, ey, cd, sd, first_mask);
+            } else {
 #pragma unroll
-            for (int r = 0; r < NC - 1; ++r) {
-                float x = xs, y = ys;
+                for (int r = 0; r < NC - 1; ++r) {
+                    float x = xs, y = ys;
 #pragma unroll
-                for (int s = 0; s < S; ++s) { x = x + cd[s]; y = y + sd[s]; }
-                const float xb = wave_below(x), yb = wave_below(y);
-                xs = first ? ex : xb;
-                ys = first ? ey : yb;
+                    for (int s = 0; s < S; ++s) { x = x + cd[s]; y = y + sd[s]; }
+                    const float xb = wave_below(x), yb = wave_below(y);
+                    xs = first ? ex : xb;
+                    ys = first ? ey : yb;
+                }
             }
 
             OCD_STAMP(3);                                  // position recurrence
@@ -420,14 +435,21 @@ mpc_chunk_kernel(const KernelParams p)
                 // ===== backward =====
                 // position adjoint arriving at the END of the chunk (from the later chunks)
                 float LxE = 0.0f, LyE = 0.0f;
+                if constexpr (asm_chains) {
+                    float qxa[S], qya[S];
 #pragma unroll
-                for (int r = 0; r < NC - 1; ++r) {
-                    float Lx = LxE, Ly = LyE;
+                    for (int s = 0; s < S; ++s) { qxa[s] = q[s].qx; qya[s] = q[s].qy; }
+                    chunk_bwd_xy<S, NC - 1>(LxE, LyE, qxa, qya, last_mask);
+                } else {
 #pragma unroll
-                    for (int s = S - 1; s >= 0; --s) { Lx = q[s].qx + Lx; Ly = q[s].qy + Ly; }
-                    const float xa = wave_above(Lx), ya = wave_above(Ly);
-                    LxE = last ? 0.0f : xa;
-                    LyE = last ? 0.0f : ya;
+                    for (int r = 0; r < NC - 1; ++r) {
+                        float Lx = LxE, Ly = LyE;
+#pragma unroll
+                        for (int s = S - 1; s >= 0; --s) { Lx = q[s].qx + Lx; Ly = q[s].qy + Ly; }
+                        const float xa = wave_above(Lx), ya = wave_above(Ly);
+                        LxE = last ? 0.0f : xa;
+                        LyE = last ? 0.0f : ya;
+                    }
                 }
                 OCD_STAMP(8);                              // position adjoint recurrence
                 float tau[S], gv1[S], gA1[S];
@@ -448,21 +470,28 @@ mpc_chunk_kernel(const KernelParams p)
                 }
                 // speed / heading adjoint arriving at the end of the chunk
                 float LvE = 0.0f, LthE = 0.0f;
+                if constexpr (asm_chains) {
+                    float qva[S], qtha[S];
 #pragma unroll
-                for (int r = 0; r < NC - 1; ++r) {
-                    float Lv = LvE, Lth = LthE;
+                    for (int s = 0; s < S; ++s) { qva[s] = q[s].qv; qtha[s] = q[s].qth; }
+                    chunk_bwd_vth<S, NC - 1>(LvE, LthE, qva, qtha, gA1, gv1, vpre, tau, fr, dt, last_mask);
+                } else {
 #pragma unroll
-                    for (int s = S - 1; s >= 0; --s) {
-                        const float Av_ = q[s].qv + Lv;
-                        const float gA_ = gA1[s] + Av_ * dt;
-                        const float gv2_ = (-gA_) * fr;
-                        const float gv3_ = (gv2_ * 2.0f) * vpre[s];
-                        Lv = (gv1[s] + Av_) + gv3_;
-                        Lth = (q[s].qth + Lth) + tau[s];
+                    for (int r = 0; r < NC - 1; ++r) {
+                        float Lv = LvE, Lth = LthE;
+#pragma unroll
+                        for (int s = S - 1; s >= 0; --s) {
+                            const float Av_ = q[s].qv + Lv;
+                            const float gA_ = gA1[s] + Av_ * dt;
+                            const float gv2_ = (-gA_) * fr;
+                            const float gv3_ = (gv2_ * 2.0f) * vpre[s];
+                            Lv = (gv1[s] + Av_) + gv3_;
+                            Lth = (q[s].qth + Lth) + tau[s];
+                        }
+                        const float va = wave_above(Lv), ta = wave_above(Lth);
+                        LvE = last ? 0.0f : va;
+                        LthE = last ? 0.0f : ta;
                     }
-                    const float va = wave_above(Lv), ta = wave_above(Lth);
-                    LvE = last ? 0.0f : va;
-                    LthE = last ? 0.0f : ta;
                 }
                 OCD_STAMP(9);                              // Jacobian products, speed / heading adjoint recurrence
                 {
