@@ -1,4 +1,4 @@
-// ocd_chunk_chains.h -- hand-scheduled horizon recurrences of the chunked kernel (V_CHUNK) for chunk sizes 2 and 3.
+// ocd_chunk_chains.h -- hand-scheduled horizon recurrences of the chunked kernel (V_CHUNK), chunk sizes 2, 3 and 5.
 //
 // A recurrence round of the chunked mapping walks the lane's S steps and hands the chunk's end value to the
 // neighbouring lane with the segment-boundary value selected in.  hipcc compiles the hand-over as v_mov_b32_dpp +
@@ -31,8 +31,12 @@
 
 namespace ocd {
 
+// the forward chains and the adjoint position chain exist for S = 2, 3, 5; the adjoint speed / heading chain for S = 2, 3
+// (at S = 5 it would need 40 asm operands; the limit is 30)
 template <int S, int NR> struct chunk_chain_supported {
-    static constexpr bool value = (S == 2 || S == 3) && (NR == 1 || NR == 2 || NR == 4 || NR == 7 || NR == 8 || NR == 12);
+    static constexpr bool rounds = NR == 1 || NR == 2 || NR == 4 || NR == 7 || NR == 8 || NR == 12;
+    static constexpr bool value = (S == 2 || S == 3 || S == 5) && rounds;
+    static constexpr bool bwd_vth = (S == 2 || S == 3) && rounds;
 };
 
 // one speed step:  v <- v + (a_c - fr * (v * v)) * dt
@@ -62,7 +66,7 @@ __device__ __forceinline__ void chunk_fwd_vth(float &v, float &th, float ev, flo
                      : "vcc");
         OCD_CHUNK_ROUNDS(NR, OCD_STMT);
 #undef OCD_STMT
-    } else {
+    } else if constexpr (S == 3) {
 #define OCD_STMT(REP)                                                                                     \
         asm volatile("s_mov_b64 vcc, %[m]\n"                                                              \
                      REP("v_add_f32 %[thn], %[thn], %[wd1]\n"                                             \
@@ -74,6 +78,25 @@ __device__ __forceinline__ void chunk_fwd_vth(float &v, float &th, float ev, flo
                      : [v] "+&v"(v), [th] "+&v"(th), [thn] "+&v"(thn), [t] "=&v"(tmp)                       \
                      : [ac0] "v"(ac[0]), [ac1] "v"(ac[1]), [ac2] "v"(ac[2]), [wd0] "v"(wd[0]), [wd1] "v"(wd[1]), \
                        [wd2] "v"(wd[2]), [ev] "v"(ev), [eth] "v"(eth), [fr] "s"(fr), [dt] "s"(dt), [m] "s"(first_mask) \
+                     : "vcc");
+        OCD_CHUNK_ROUNDS(NR, OCD_STMT);
+#undef OCD_STMT
+    } else {
+        static_assert(S == 5, "chunk sizes 2, 3, 5");
+#define OCD_STMT(REP)                                                                                     \
+        asm volatile("s_mov_b64 vcc, %[m]\n"                                                              \
+                     REP("v_add_f32 %[thn], %[thn], %[wd1]\n"                                             \
+                         "v_add_f32 %[thn], %[thn], %[wd2]\n"                                             \
+                         "v_add_f32 %[thn], %[thn], %[wd3]\n"                                             \
+                         "v_add_f32 %[thn], %[thn], %[wd4]\n"                                             \
+                         OCD_VSTEP("ac0") OCD_VSTEP("ac1") OCD_VSTEP("ac2") OCD_VSTEP("ac3") OCD_VSTEP("ac4") \
+                         "v_cndmask_b32_dpp %[th], %[thn], %[eth], vcc" OCD_WAVE_SHR                      \
+                         "v_add_f32 %[thn], %[th], %[wd0]\n"                                              \
+                         "v_cndmask_b32_dpp %[v], %[v], %[ev], vcc" OCD_WAVE_SHR)                         \
+                     : [v] "+&v"(v), [th] "+&v"(th), [thn] "+&v"(thn), [t] "=&v"(tmp)                    \
+                     : [ac0] "v"(ac[0]), [ac1] "v"(ac[1]), [ac2] "v"(ac[2]), [ac3] "v"(ac[3]), [ac4] "v"(ac[4]), \
+                       [wd0] "v"(wd[0]), [wd1] "v"(wd[1]), [wd2] "v"(wd[2]), [wd3] "v"(wd[3]), [wd4] "v"(wd[4]), \
+                       [ev] "v"(ev), [eth] "v"(eth), [fr] "s"(fr), [dt] "s"(dt), [m] "s"(first_mask)      \
                      : "vcc");
         OCD_CHUNK_ROUNDS(NR, OCD_STMT);
 #undef OCD_STMT
@@ -101,7 +124,7 @@ __device__ __forceinline__ void chunk_fwd_xy(float &x, float &y, float ex, float
                      : "vcc");
         OCD_CHUNK_ROUNDS(NR, OCD_STMT);
 #undef OCD_STMT
-    } else {
+    } else if constexpr (S == 3) {
 #define OCD_STMT(REP)                                                                                     \
         asm volatile("s_mov_b64 vcc, %[m]\n"                                                              \
                      REP("v_add_f32 %[xn], %[xn], %[cd1]\n"                                               \
@@ -115,6 +138,29 @@ __device__ __forceinline__ void chunk_fwd_xy(float &x, float &y, float ex, float
                      : [x] "+&v"(x), [y] "+&v"(y), [xn] "+&v"(xn)                                           \
                      : [cd0] "v"(cd[0]), [cd1] "v"(cd[1]), [cd2] "v"(cd[2]), [sd0] "v"(sd[0]), [sd1] "v"(sd[1]), \
                        [sd2] "v"(sd[2]), [ex] "v"(ex), [ey] "v"(ey), [m] "s"(first_mask)                  \
+                     : "vcc");
+        OCD_CHUNK_ROUNDS(NR, OCD_STMT);
+#undef OCD_STMT
+    } else {
+        static_assert(S == 5, "chunk sizes 2, 3, 5");
+#define OCD_STMT(REP)                                                                                     \
+        asm volatile("s_mov_b64 vcc, %[m]\n"                                                              \
+                     REP("v_add_f32 %[xn], %[xn], %[cd1]\n"                                               \
+                         "v_add_f32 %[xn], %[xn], %[cd2]\n"                                               \
+                         "v_add_f32 %[xn], %[xn], %[cd3]\n"                                               \
+                         "v_add_f32 %[xn], %[xn], %[cd4]\n"                                               \
+                         "v_add_f32 %[y], %[y], %[sd0]\n"                                                 \
+                         "v_add_f32 %[y], %[y], %[sd1]\n"                                                 \
+                         "v_add_f32 %[y], %[y], %[sd2]\n"                                                 \
+                         "v_add_f32 %[y], %[y], %[sd3]\n"                                                 \
+                         "v_add_f32 %[y], %[y], %[sd4]\n"                                                 \
+                         "v_cndmask_b32_dpp %[x], %[xn], %[ex], vcc" OCD_WAVE_SHR                         \
+                         "v_add_f32 %[xn], %[x], %[cd0]\n"                                                \
+                         "v_cndmask_b32_dpp %[y], %[y], %[ey], vcc" OCD_WAVE_SHR)                         \
+                     : [x] "+&v"(x), [y] "+&v"(y), [xn] "+&v"(xn)                                        \
+                     : [cd0] "v"(cd[0]), [cd1] "v"(cd[1]), [cd2] "v"(cd[2]), [cd3] "v"(cd[3]), [cd4] "v"(cd[4]), \
+                       [sd0] "v"(sd[0]), [sd1] "v"(sd[1]), [sd2] "v"(sd[2]), [sd3] "v"(sd[3]), [sd4] "v"(sd[4]), \
+                       [ex] "v"(ex), [ey] "v"(ey), [m] "s"(first_mask)                                    \
                      : "vcc");
         OCD_CHUNK_ROUNDS(NR, OCD_STMT);
 #undef OCD_STMT
@@ -144,7 +190,7 @@ __device__ __forceinline__ void chunk_bwd_xy(float &Lx, float &Ly, const float (
                      : "vcc");
         OCD_CHUNK_ROUNDS(NR, OCD_STMT);
 #undef OCD_STMT
-    } else {
+    } else if constexpr (S == 3) {
 #define OCD_STMT(REP)                                                                                     \
         asm volatile("s_mov_b64 vcc, %[m]\n"                                                              \
                      REP("v_add_f32 %[xn], %[qx1], %[xn]\n"                                               \
@@ -158,6 +204,29 @@ __device__ __forceinline__ void chunk_bwd_xy(float &Lx, float &Ly, const float (
                      : [Lx] "+&v"(Lx), [Ly] "+&v"(Ly), [xn] "+&v"(xn)                                       \
                      : [qx0] "v"(qx[0]), [qx1] "v"(qx[1]), [qx2] "v"(qx[2]), [qy0] "v"(qy[0]), [qy1] "v"(qy[1]), \
                        [qy2] "v"(qy[2]), [z] "v"(zero), [m] "s"(last_mask)                                \
+                     : "vcc");
+        OCD_CHUNK_ROUNDS(NR, OCD_STMT);
+#undef OCD_STMT
+    } else {
+        static_assert(S == 5, "chunk sizes 2, 3, 5");
+#define OCD_STMT(REP)                                                                                     \
+        asm volatile("s_mov_b64 vcc, %[m]\n"                                                              \
+                     REP("v_add_f32 %[xn], %[qx3], %[xn]\n"                                               \
+                         "v_add_f32 %[xn], %[qx2], %[xn]\n"                                               \
+                         "v_add_f32 %[xn], %[qx1], %[xn]\n"                                               \
+                         "v_add_f32 %[xn], %[qx0], %[xn]\n"                                               \
+                         "v_add_f32 %[Ly], %[qy4], %[Ly]\n"                                               \
+                         "v_add_f32 %[Ly], %[qy3], %[Ly]\n"                                               \
+                         "v_add_f32 %[Ly], %[qy2], %[Ly]\n"                                               \
+                         "v_add_f32 %[Ly], %[qy1], %[Ly]\n"                                               \
+                         "v_add_f32 %[Ly], %[qy0], %[Ly]\n"                                               \
+                         "v_cndmask_b32_dpp %[Lx], %[xn], %[z], vcc" OCD_WAVE_SHL                         \
+                         "v_add_f32 %[xn], %[qx4], %[Lx]\n"                                               \
+                         "v_cndmask_b32_dpp %[Ly], %[Ly], %[z], vcc" OCD_WAVE_SHL)                        \
+                     : [Lx] "+&v"(Lx), [Ly] "+&v"(Ly), [xn] "+&v"(xn)                                    \
+                     : [qx0] "v"(qx[0]), [qx1] "v"(qx[1]), [qx2] "v"(qx[2]), [qx3] "v"(qx[3]), [qx4] "v"(qx[4]), \
+                       [qy0] "v"(qy[0]), [qy1] "v"(qy[1]), [qy2] "v"(qy[2]), [qy3] "v"(qy[3]), [qy4] "v"(qy[4]), \
+                       [z] "v"(zero), [m] "s"(last_mask)                                                  \
                      : "vcc");
         OCD_CHUNK_ROUNDS(NR, OCD_STMT);
 #undef OCD_STMT

@@ -74,9 +74,10 @@ mpc_chunk_kernel(const KernelParams p)
     const unsigned long long last_mask = __ballot(last), first_mask = __ballot(first);
     const unsigned long long real_mask = live_mask & ~last_mask;        // the lanes whose padding steps (if any) count
 #ifdef OCD_NO_ASM_CHAINS
-    constexpr bool asm_chains = false;
+    constexpr bool asm_chains = false, asm_bwd_vth = false;
 #else
     constexpr bool asm_chains = chunk_chain_supported<S, NC - 1>::value;   // hand-scheduled rounds (ocd_chunk_chains.h)
+    constexpr bool asm_bwd_vth = chunk_chain_supported<S, NC - 1>::bwd_vth;
 #endif
 
     const float dt = d.dt, dt2 = d.dt_sq, fr = d.ego_friction, lr = d.learning_rate;
@@ -470,7 +471,7 @@ mpc_chunk_kernel(const KernelParams p)
                 }
                 // speed / heading adjoint arriving at the end of the chunk
                 float LvE = 0.0f, LthE = 0.0f;
-                if constexpr (asm_chains) {
+                if constexpr (asm_bwd_vth) {
                     float qva[S], qtha[S];
 #pragma unroll
                     for (int s = 0; s < S; ++s) { qva[s] = q[s].qv; qtha[s] = q[s].qth; }
