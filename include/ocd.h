@@ -172,6 +172,10 @@ int32_t ocd_scenario_set_option(ocd_scenario *scn, const char *name, int32_t val
  * all zero before the first launch. */
 int32_t ocd_scenario_last_launch(const ocd_scenario *scn, int32_t info[8]);
 
+/* The same record for a launch of n_problems trajectories on a device of n_cus compute units (0 = 256, MI355X) WITHOUT
+ * launching anything: pure host logic, needs no device (the launch rules are unit-tested through it). */
+int32_t ocd_scenario_plan_launch(const ocd_scenario *scn, int64_t n_problems, int32_t n_cus, int32_t info[8]);
+
 /*
  * Terminal value of the planner: NaivePlanner(leaf_evaluation=ValueFeature(...).interpolate_value(t))
  * (naive_planner.py:20,69-70; reward_design/value_interpolation.py:28-61).  When set, the reward of

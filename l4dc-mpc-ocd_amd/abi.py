@@ -93,6 +93,7 @@ HIP_SYMBOLS = [
     ("ocd_scenario_destroy", None, [_VP]),
     ("ocd_scenario_set_option", C.c_int32, [_VP, C.c_char_p, C.c_int32]),
     ("ocd_scenario_last_launch", C.c_int32, [_VP, _I]),
+    ("ocd_scenario_plan_launch", C.c_int32, [_VP, C.c_int64, C.c_int32, _I]),
     ("ocd_scenario_set_leaf_value", C.c_int32, [_VP, _F, C.c_int32, _F, C.c_int32, _F, C.c_int32, _F, C.c_int32]),
     ("ocd_plan_batch", C.c_int32,
      [_VP, _VP, _VP, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, _VP]),
@@ -165,3 +166,20 @@ def check(lib: C.CDLL, status: int) -> None:
     if status != OCD_OK:
         msg = lib.ocd_last_error()
         raise OcdError(status, msg.decode() if msg else "")
+
+
+LAUNCH_MAPPINGS = {0: "none", 1: "lds_windows", 2: "dpp_rows", 3: "one_wavefront", 4: "chunked"}
+
+
+def decode_launch(info) -> dict:
+    """The int32[8] record of ocd_scenario_last_launch / ocd_scenario_plan_launch (include/ocd.h) as a dict."""
+    return {"scan_mode": info[0], "mapping": LAUNCH_MAPPINGS.get(info[0], "?"), "chunk": info[1],
+            "trajectories_per_wavefront": info[2], "workgroups": info[3], "build_wavefronts_per_simd": info[4],
+            "specialised_horizon": info[5], "terminal_value": bool(info[6]), "wavefronts_per_workgroup": info[7]}
+
+
+def plan_launch(lib, handle, n_problems: int, n_cus: int = 0) -> dict:
+    """What a launch of n_problems trajectories would choose on a device of n_cus compute units (0 = 256); no device needed."""
+    info = (C.c_int32 * 8)()
+    check(lib, lib.ocd_scenario_plan_launch(handle, int(n_problems), int(n_cus), info))
+    return decode_launch(info)

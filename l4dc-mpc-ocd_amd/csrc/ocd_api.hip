@@ -242,6 +242,35 @@ int32_t ocd_scenario_last_launch(const ocd_scenario *scn, int32_t info[8])
     return OCD_OK;
 }
 
+int32_t ocd_scenario_plan_launch(const ocd_scenario *scn, int64_t n_problems, int32_t n_cus, int32_t info[8])
+{
+    if (!scn || !info) return fail(OCD_ERR_INVALID_ARG, "scenario or info is NULL");
+    if (n_problems < 1) return fail(OCD_ERR_INVALID_ARG, "n_problems %lld < 1", (long long)n_problems);
+    if (n_cus < 0) return fail(OCD_ERR_INVALID_ARG, "n_cus %d < 0", n_cus);
+    ocd::KernelParams p;
+    base_params(scn, p);
+    p.mode = ocd::OCD_MODE_PLAN;
+    p.n_problems = n_problems;
+    p.n_cus = n_cus > 0 ? n_cus : 256;
+    p.dry_run = 1;
+    if (!scn->leaf_host.empty()) {                       // (never dereferenced in a dry run)
+        const int ng = scn->leaf_n[0] + scn->leaf_n[1] + scn->leaf_n[2];
+        p.leaf.grid = scn->leaf_host.data();
+        p.leaf.values = scn->leaf_host.data() + ng;
+        for (int k = 0; k < 3; ++k) p.leaf.n[k] = scn->leaf_n[k];
+        p.leaf.proj_kind = scn->leaf_proj;
+    }
+    int32_t rec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    p.launch_info = rec;
+    bool supported = false;
+    (void)ocd::launch_mpc_dispatch(scn->desc.horizon, scn->desc.n_cars - 1, kernel_L(scn->desc), p, nullptr, &supported);
+    if (!supported)
+        return fail(OCD_ERR_UNSUPPORTED, "no compiled kernel for horizon %d with %d scripted cars (see OCD_PAIR_TABLE)",
+                    scn->desc.horizon, scn->desc.n_cars - 1);
+    std::memcpy(info, rec, sizeof(rec));
+    return OCD_OK;
+}
+
 int32_t ocd_scenario_set_leaf_value(ocd_scenario *scn, const float *grid0, int32_t n0,
                                     const float *grid1, int32_t n1, const float *grid2, int32_t n2,
                                     const float *values, int32_t proj_kind)

@@ -624,10 +624,10 @@ static hipError_t launch_chunk(const KernelParams &p_in, hipStream_t st)
     const bool lat = L > 0 && NO > 0 && !p.no_skips && !p.no_unify && !p.no_latency_build && (long long)blocks <= simds;
     const bool occ3 = !lat && (long long)blocks >= 3 * simds && !p.no_latency_build;
     note_launch(p, 4, S, segs, blocks, lat ? 1 : (occ3 ? 3 : 0), HT, 0, 1);
-    if (lat) hipLaunchKernelGGL((mpc_chunk_kernel<HT, NO, L, S, true>), dim3(blocks), dim3(64), 0, st, p);
-    else if (occ3) hipLaunchKernelGGL((mpc_chunk_kernel<HT, NO, L, S, false, true>), dim3(blocks), dim3(64), 0, st, p);
-    else hipLaunchKernelGGL((mpc_chunk_kernel<HT, NO, L, S>), dim3(blocks), dim3(64), 0, st, p);
-    return hipGetLastError();
+    if (lat) OCD_LAUNCH((mpc_chunk_kernel<HT, NO, L, S, true>), dim3(blocks), dim3(64), 0, st, p);
+    else if (occ3) OCD_LAUNCH((mpc_chunk_kernel<HT, NO, L, S, false, true>), dim3(blocks), dim3(64), 0, st, p);
+    else OCD_LAUNCH((mpc_chunk_kernel<HT, NO, L, S>), dim3(blocks), dim3(64), 0, st, p);
+    return launch_status(p);
 }
 
 // Cost of chunk size S for n trajectories (round-3 sweeps, tools/sweep_sizes.sh, profiles/r03_sweep_sizes.txt):

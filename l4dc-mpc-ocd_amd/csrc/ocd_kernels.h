@@ -70,7 +70,13 @@ struct KernelParams {
     int32_t n_cus;             // compute units of the device (launch shape heuristics)
     unsigned long long *debug; // diagnostic builds only (OCD_STAMPS): per-wavefront cycle totals, else nullptr
     int32_t *launch_info;      // HOST pointer or nullptr: the launcher records its choice here (ocd_scenario_last_launch)
+    int32_t dry_run;           // 1 = choose and record, launch nothing (ocd_scenario_plan_launch: no device needed)
 };
+
+// the launchers' only way to start a planner kernel: nothing is launched in a dry run
+#define OCD_LAUNCH(KERNEL, GRID, BLOCK, LDS, STREAM, P) \
+    do { if (!(P).dry_run) hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, P); } while (0)
+static inline hipError_t launch_status(const KernelParams &p) { return p.dry_run ? hipSuccess : hipGetLastError(); }
 
 // what a launch chose: {scan mode 1..4, chunk size S (V_CHUNK) else 0, trajectories per wavefront, workgroups,
 // wavefronts per SIMD the build is compiled for (1 = the latency build LAT, 0 = unconstrained), H specialised (0 =

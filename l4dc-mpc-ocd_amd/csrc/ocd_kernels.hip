@@ -1013,15 +1013,15 @@ static hipError_t launch_mpc(const KernelParams &p_in, hipStream_t st)
         if (leaf && variant == V_SEG && blocks <= 4 * simds) {
             p.leaf.grid_in_lds = 1;
             note_launch(p, 3, 0, segs, blocks, 1, HT, 1, 1);
-            hipLaunchKernelGGL((mpc_kernel<HT, NO, L, V_SEG, true, true>), dim3(blocks), dim3(64), leaf_lds, st, p);
-            return hipGetLastError();
+            OCD_LAUNCH((mpc_kernel<HT, NO, L, V_SEG, true, true>), dim3(blocks), dim3(64), leaf_lds, st, p);
+            return launch_status(p);
         }
         if (leaf && variant == V_ROW && (long long)blocks * K <= simds) {
             const size_t lds = (size_t)2 * K * G.SEL_FLOATS * sizeof(float) + leaf_lds;
             p.leaf.grid_in_lds = 1;
             note_launch(p, 2, 0, segs, blocks, 1, HT, 1, K);
-            hipLaunchKernelGGL((mpc_kernel<HT, NO, L, V_ROW, true, true>), dim3(blocks), dim3(64 * K), lds, st, p);
-            return hipGetLastError();
+            OCD_LAUNCH((mpc_kernel<HT, NO, L, V_ROW, true, true>), dim3(blocks), dim3(64 * K), lds, st, p);
+            return launch_status(p);
         }
     }
     if (leaf) {                                                        // generic kernel, densest packing
@@ -1030,32 +1030,32 @@ static hipError_t launch_mpc(const KernelParams &p_in, hipStream_t st)
         const size_t base = ((size_t)K * G.WAVE_FLOATS + (size_t)2 * K * G.SEL_FLOATS) * sizeof(float);
         p.leaf.grid_in_lds = (base + leaf_lds <= 64 * 1024) ? 1 : 0;   // (the default dynamic-LDS limit of a launch)
         note_launch(p, 1, 0, p.segs_used, gblocks, 0, 0, 1, K);
-        hipLaunchKernelGGL((mpc_kernel<0, NO, L, V_LDS, true>), dim3(gblocks), dim3(64 * K), base + (p.leaf.grid_in_lds ? leaf_lds : 0), st, p);
-        return hipGetLastError();
+        OCD_LAUNCH((mpc_kernel<0, NO, L, V_LDS, true>), dim3(gblocks), dim3(64 * K), base + (p.leaf.grid_in_lds ? leaf_lds : 0), st, p);
+        return launch_status(p);
     }
     if constexpr (HT > 0) {
         if (variant == V_SEG) {
             if constexpr (HT * 3 <= 64) {
                 note_launch(p, 3, 0, segs, blocks, (lat && blocks <= 4 * simds) ? 1 : 0, HT, 0, 1);
-                if (lat && blocks <= 4 * simds) hipLaunchKernelGGL((mpc_kernel<HT, NO, L, V_SEG, false, true>), dim3(blocks), dim3(64), 0, st, p);
-                else hipLaunchKernelGGL((mpc_kernel<HT, NO, L, V_SEG>), dim3(blocks), dim3(64), 0, st, p);
+                if (lat && blocks <= 4 * simds) OCD_LAUNCH((mpc_kernel<HT, NO, L, V_SEG, false, true>), dim3(blocks), dim3(64), 0, st, p);
+                else OCD_LAUNCH((mpc_kernel<HT, NO, L, V_SEG>), dim3(blocks), dim3(64), 0, st, p);
             }
-            return hipGetLastError();
+            return launch_status(p);
         }
         if (variant == V_ROW) {
             const size_t lds = (size_t)2 * K * G.SEL_FLOATS * sizeof(float);
             if constexpr (HT <= 16) {
                 note_launch(p, 2, 0, segs, blocks, (lat && (long long)blocks * K <= simds) ? 1 : 0, HT, 0, K);
-                if (lat && (long long)blocks * K <= simds) hipLaunchKernelGGL((mpc_kernel<HT, NO, L, V_ROW, false, true>), dim3(blocks), dim3(64 * K), lds, st, p);
-                else hipLaunchKernelGGL((mpc_kernel<HT, NO, L, V_ROW>), dim3(blocks), dim3(64 * K), lds, st, p);
+                if (lat && (long long)blocks * K <= simds) OCD_LAUNCH((mpc_kernel<HT, NO, L, V_ROW, false, true>), dim3(blocks), dim3(64 * K), lds, st, p);
+                else OCD_LAUNCH((mpc_kernel<HT, NO, L, V_ROW>), dim3(blocks), dim3(64 * K), lds, st, p);
             }
-            return hipGetLastError();
+            return launch_status(p);
         }
     }
     const size_t lds = ((size_t)K * G.WAVE_FLOATS + (size_t)2 * K * G.SEL_FLOATS) * sizeof(float);
     note_launch(p, 1, 0, segs, blocks, 0, HT, 0, K);
-    hipLaunchKernelGGL((mpc_kernel<HT, NO, L, V_LDS>), dim3(blocks), dim3(64 * K), lds, st, p);
-    return hipGetLastError();
+    OCD_LAUNCH((mpc_kernel<HT, NO, L, V_LDS>), dim3(blocks), dim3(64 * K), lds, st, p);
+    return launch_status(p);
 }
 
 #define OCD_CASE(HH, NN, LL) if (H == HH && NO == NN && L == LL) return launch_mpc<HH, NN, LL>(p, st);

@@ -100,16 +100,16 @@ class Engine(DeviceOps):
         """Per-handle tuning / bookkeeping option (include/ocd.h: ocd_scenario_set_option)."""
         abi.check(self.lib, self.lib.ocd_scenario_set_option(self._h, name.encode(), int(value)))
 
-    _MODES = {0: "none", 1: "lds_windows", 2: "dpp_rows", 3: "one_wavefront", 4: "chunked"}
-
     def last_launch(self) -> dict:
         """What the most recent planner launch of this handle chose (include/ocd.h: ocd_scenario_last_launch)."""
         import ctypes as C
         info = (C.c_int32 * 8)()
         abi.check(self.lib, self.lib.ocd_scenario_last_launch(self._h, info))
-        return {"scan_mode": info[0], "mapping": self._MODES.get(info[0], "?"), "chunk": info[1],
-                "trajectories_per_wavefront": info[2], "workgroups": info[3], "build_wavefronts_per_simd": info[4],
-                "specialised_horizon": info[5], "terminal_value": bool(info[6]), "wavefronts_per_workgroup": info[7]}
+        return abi.decode_launch(info)
+
+    def plan_launch(self, n_problems: int, n_cus: int = 0) -> dict:
+        """What a launch of n_problems trajectories would choose (include/ocd.h: ocd_scenario_plan_launch)."""
+        return abi.plan_launch(self.lib, self._h, n_problems, n_cus)
 
     def set_leaf_value(self, disc_grid, values, proj_kind: int = 0) -> None:
         """Terminal value of the planner: ValueFeature(disc_grid, v_grids[t]) as leaf_evaluation

@@ -1,0 +1,116 @@
+"""The launch rules of the planner (which lane mapping, chunk size, packing and build a batch gets:
+launch_mpc / launch_chunk_dispatch) pinned through ocd_scenario_plan_launch -- pure host logic
+of the C-ABI library, no device needed.  The expected rows are the measured winners of profiles/r03_sweep_sizes.txt."""
+import ctypes as C
+
+import pytest
+
+from l4dc_mpc_ocd_amd import abi, scenarios
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return abi.load_hip_library()
+
+
+def plan(lib, scn, n, n_cus=0, leaf=False, **opts):
+    h = C.c_void_p()
+    abi.check(lib, lib.ocd_scenario_create(C.byref(scn.desc), C.byref(h)))
+    try:
+        for k, v in opts.items():
+            abi.check(lib, lib.ocd_scenario_set_option(h, k.encode(), v))
+        if leaf:
+            import numpy as np
+            g = [np.linspace(-1, 1, 4, dtype=np.float32) for _ in range(3)]
+            vals = np.zeros(64, dtype=np.float32)
+            fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+            abi.check(lib, lib.ocd_scenario_set_leaf_value(h, fp(g[0]), 4, fp(g[1]), 4, fp(g[2]), 4, fp(vals), 1))
+        return abi.plan_launch(lib, h, n, n_cus)
+    finally:
+        lib.ocd_scenario_destroy(h)
+
+
+def row(ll):
+    return (ll["mapping"], ll["chunk"], ll["trajectories_per_wavefront"], ll["workgroups"], ll["build_wavefronts_per_simd"])
+
+
+# (scenario, horizon, trajectories) -> (mapping, chunk size, trajectories per wavefront, workgroups, build)
+RULES = [
+    # config 2 / config 3 and multiples (H = 10, one scripted car)
+    ("finite_horizon", 10, 128, ("dpp_rows", 0, 1, 128, 1)),
+    ("local_opt", 10, 2048, ("one_wavefront", 0, 2, 1024, 1)),
+    ("local_opt", 10, 3072, ("chunked", 2, 3, 1024, 1)),
+    ("local_opt", 10, 4096, ("chunked", 2, 4, 1024, 1)),
+    ("local_opt", 10, 8192, ("chunked", 2, 4, 2048, 0)),
+    ("local_opt", 10, 32768, ("chunked", 2, 4, 8192, 3)),
+    # config 4's shape (H = 15, two scripted cars): per-GPU share, intermediate sizes, whole
+    ("replanning", 15, 1024, ("one_wavefront", 0, 1, 1024, 1)),
+    ("replanning", 15, 2048, ("chunked", 2, 2, 1024, 1)),
+    ("replanning", 15, 4096, ("chunked", 3, 4, 1024, 1)),
+    ("replanning", 15, 6144, ("chunked", 5, 6, 1024, 1)),
+    ("replanning", 15, 8192, ("chunked", 3, 4, 2048, 0)),
+    ("replanning", 15, 16384, ("chunked", 3, 4, 4096, 3)),
+    # config 5's shape (H = 25): the chunked kernel at every size, the smallest chunk that fits one wavefront per SIMD
+    ("merging", 25, 1, ("chunked", 2, 1, 1, 1)),
+    ("merging", 25, 1024, ("chunked", 2, 1, 1024, 1)),
+    ("merging", 25, 2048, ("chunked", 3, 2, 1024, 1)),
+    ("merging", 25, 4096, ("chunked", 5, 4, 1024, 1)),
+    ("merging", 25, 32768, ("chunked", 5, 4, 8192, 3)),
+    # the reference's own horizons: DPP rows while trajectories x K fit the SIMDs, then all initialisations in one wavefront
+    ("finite_horizon", 5, 3, ("dpp_rows", 0, 1, 3, 1)),
+    ("finite_horizon", 5, 2048, ("one_wavefront", 0, 2, 1024, 1)),
+    ("finite_horizon", 6, 300, ("dpp_rows", 0, 1, 300, 1)),
+    # a horizon without a specialised kernel: run-time H, LDS windows
+    ("finite_horizon", 12, 100, ("lds_windows", 0, 1, 100, 0)),
+]
+
+
+@pytest.mark.parametrize("name,H,n,expect", RULES, ids=[f"{r[0]}-H{r[1]}-n{r[2]}" for r in RULES])
+def test_launch_rule(lib, name, H, n, expect):
+    ll = plan(lib, scenarios.SCENARIOS[name](horizon=H), n)
+    assert row(ll) == expect, ll
+    assert ll["specialised_horizon"] == (0 if expect[0] == "lds_windows" and H == 12 else H)
+    assert not ll["terminal_value"]
+
+
+def test_forced_shapes_and_fallbacks(lib):
+    scn = scenarios.local_opt(horizon=10)
+    assert row(plan(lib, scn, 500, scan_mode=1))[0] == "lds_windows"
+    assert row(plan(lib, scn, 500, scan_mode=4, chunk_size=5)) == ("chunked", 5, 1, 500, 1)
+    assert row(plan(lib, scn, 5000, scan_mode=4, chunk_size=5, no_latency_build=1))[4] == 0
+    assert row(plan(lib, scn, 500, scan_mode=3, segs_per_wave=2))[:3] == ("one_wavefront", 0, 2)
+    # a chunk size that is not compiled for the shape: like any mode the scenario cannot use, the LDS windows
+    assert row(plan(lib, scn, 500, scan_mode=4, chunk_size=4))[0] == "lds_windows"
+    # mode 2 needs H <= 16, mode 3 K * H <= 64: H = 25 falls back to the LDS windows
+    scn25 = scenarios.merging(horizon=25)
+    assert row(plan(lib, scn25, 64, scan_mode=2))[0] == "lds_windows"
+    assert row(plan(lib, scn25, 64, scan_mode=3))[0] == "lds_windows"
+
+
+def test_terminal_value_builds(lib):
+    """The terminal value rides in the specialised DPP builds at the reference's horizons 5 / 6, else in the generic kernel."""
+    a = plan(lib, scenarios.finite_horizon(horizon=5), 64, leaf=True)
+    assert a["terminal_value"] and a["mapping"] == "dpp_rows" and a["specialised_horizon"] == 5
+    b = plan(lib, scenarios.finite_horizon(horizon=5), 2048, leaf=True)
+    assert b["terminal_value"] and b["mapping"] == "one_wavefront"
+    c = plan(lib, scenarios.finite_horizon(horizon=10), 64, leaf=True)
+    assert c["terminal_value"] and c["mapping"] == "lds_windows" and c["specialised_horizon"] == 0
+
+
+def test_smaller_device(lib):
+    """Rules scale with the number of SIMDs: on 64 compute units config 3's 2 048 trajectories no longer fit one
+    wavefront per SIMD under any one-lane-per-step mapping."""
+    scn = scenarios.local_opt(horizon=10)
+    assert row(plan(lib, scn, 512, n_cus=64)) == ("one_wavefront", 0, 2, 256, 1)
+    assert row(plan(lib, scn, 2048, n_cus=64))[0] == "chunked"
+
+
+def test_argument_checks(lib):
+    h = C.c_void_p()
+    abi.check(lib, lib.ocd_scenario_create(C.byref(scenarios.local_opt(horizon=10).desc), C.byref(h)))
+    info = (C.c_int32 * 8)()
+    assert lib.ocd_scenario_plan_launch(h, 0, 0, info) == abi.OCD_ERR_INVALID_ARG
+    assert lib.ocd_scenario_plan_launch(h, 10, -1, info) == abi.OCD_ERR_INVALID_ARG
+    assert lib.ocd_scenario_plan_launch(None, 10, 0, info) == abi.OCD_ERR_INVALID_ARG
+    assert lib.ocd_scenario_plan_launch(h, 10, 0, None) == abi.OCD_ERR_INVALID_ARG
+    lib.ocd_scenario_destroy(h)
