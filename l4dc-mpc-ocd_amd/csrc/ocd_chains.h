@@ -26,6 +26,10 @@
 #define OCD_REP5(S) S S S S S
 #define OCD_REP9(S) OCD_REP4(S) OCD_REP5(S)
 #define OCD_REP14(S) OCD_REP9(S) OCD_REP5(S)
+#define OCD_REP0(S)
+#define OCD_REP3(S) S S S
+#define OCD_REP8(S) OCD_REP4(S) OCD_REP4(S)
+#define OCD_REP13(S) OCD_REP9(S) OCD_REP4(S)
 
 // STMT(REP) must expand to a statement using REP("...") for the round body
 #define OCD_CHAIN_ROUNDS(HT, STMT)                                   \
@@ -47,6 +51,19 @@ template <int HT> struct chain_supported { static constexpr bool value = HT == 2
 #define OCD_ROW_SHL " row_shl:1 row_mask:0xf bank_mask:0xf\n"
 #define OCD_WAVE_SHR " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
 #define OCD_WAVE_SHL " wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+
+// the same with H-2 repeats: the V_SEG chains peel their first round, in which every lane still holds the boundary value
+// -- the round reads the boundary registers directly and the recurrence registers are outputs only (no copies in)
+#define OCD_CHAIN_ROUNDS_M1(HT, STMT)                                \
+    do {                                                             \
+        if constexpr ((HT) == 2) { STMT(OCD_REP0) }                  \
+        else if constexpr ((HT) == 3) { STMT(OCD_REP1) }             \
+        else if constexpr ((HT) == 5) { STMT(OCD_REP3) }             \
+        else if constexpr ((HT) == 6) { STMT(OCD_REP4) }             \
+        else if constexpr ((HT) == 10) { STMT(OCD_REP8) }            \
+        else if constexpr ((HT) == 15) { STMT(OCD_REP13) }           \
+        else static_assert((HT) == 2, "no repeat macro for this horizon"); \
+    } while (0)
 
 // ---- forward speed / heading recurrence ----
 //   v_next = v + (a_c - fr * (v * v)) * dt ; th_next = th + wdt ; (v, th) <- (v_next, th_next) of the lane below
@@ -71,13 +88,22 @@ __device__ __forceinline__ void row_fwd_vth(float &v, float &th, float a_c, floa
 #undef OCD_STMT
 }
 
+// (v, th) are outputs: every lane starts the recurrence at (ev, eth)
 template <int HT>
 __device__ __forceinline__ void seg_fwd_vth(float &v, float &th, float ev, float eth, float a_c, float wdt, float fr,
                                             float dt, unsigned long long first_mask)
 {
-    float thn = th + wdt, tmp;
+    float thn = eth + wdt, tmp;
 #define OCD_STMT(REP)                                                                                     \
     asm volatile("s_mov_b64 vcc, %[m]\n"                                                                  \
+                 "v_mul_f32 %[t], %[ev], %[ev]\n"                                                         \
+                 "v_mul_f32 %[t], %[fr], %[t]\n"                                                          \
+                 "v_sub_f32 %[t], %[ac], %[t]\n"                                                          \
+                 "v_mul_f32 %[t], %[dt], %[t]\n"                                                          \
+                 "v_add_f32 %[t], %[ev], %[t]\n"                                                          \
+                 "v_cndmask_b32_dpp %[th], %[thn], %[eth], vcc" OCD_WAVE_SHR                              \
+                 "v_add_f32 %[thn], %[th], %[wdt]\n"                                                      \
+                 "v_cndmask_b32_dpp %[v], %[t], %[ev], vcc" OCD_WAVE_SHR                                  \
                  REP("v_mul_f32 %[t], %[v], %[v]\n"                                                       \
                      "v_mul_f32 %[t], %[fr], %[t]\n"                                                      \
                      "v_sub_f32 %[t], %[ac], %[t]\n"                                                      \
@@ -86,11 +112,11 @@ __device__ __forceinline__ void seg_fwd_vth(float &v, float &th, float ev, float
                      "v_cndmask_b32_dpp %[th], %[thn], %[eth], vcc" OCD_WAVE_SHR                          \
                      "v_add_f32 %[thn], %[th], %[wdt]\n"                                                  \
                      "v_cndmask_b32_dpp %[v], %[t], %[ev], vcc" OCD_WAVE_SHR)                             \
-                 : [v] "+&v"(v), [th] "+&v"(th), [thn] "+&v"(thn), [t] "=&v"(tmp)                           \
+                 : [v] "=&v"(v), [th] "=&v"(th), [thn] "+&v"(thn), [t] "=&v"(tmp)                        \
                  : [ac] "v"(a_c), [wdt] "v"(wdt), [ev] "v"(ev), [eth] "v"(eth), [fr] "s"(fr), [dt] "s"(dt), \
                    [m] "s"(first_mask)                                                                    \
                  : "vcc");
-    OCD_CHAIN_ROUNDS(HT, OCD_STMT);
+    OCD_CHAIN_ROUNDS_M1(HT, OCD_STMT);
 #undef OCD_STMT
 }
 
@@ -138,21 +164,26 @@ __device__ __forceinline__ void row_fwd_xy_phi0_h10(float &x, float &y, float cd
 }
 
 // V_SEG: the y chain runs half a round behind the x chain; each chain's add and select cover the other's hazard.
+// (x, y) are outputs: every lane starts at (ex, ey).
 template <int HT>
 __device__ __forceinline__ void seg_fwd_xy(float &x, float &y, float ex, float ey, float cd, float sd,
                                            unsigned long long first_mask)
 {
-    float sx, sy = y + sd;
+    float sx, sy = ey + sd;
 #define OCD_STMT(REP)                                                                                     \
     asm volatile("s_mov_b64 vcc, %[m]\n"                                                                  \
+                 "v_add_f32 %[sx], %[ex], %[cd]\n"                                                        \
+                 "v_cndmask_b32_dpp %[y], %[sy], %[ey], vcc" OCD_WAVE_SHR                                 \
+                 "v_add_f32 %[sy], %[y], %[sd]\n"                                                         \
+                 "v_cndmask_b32_dpp %[x], %[sx], %[ex], vcc" OCD_WAVE_SHR                                 \
                  REP("v_add_f32 %[sx], %[x], %[cd]\n"                                                     \
                      "v_cndmask_b32_dpp %[y], %[sy], %[ey], vcc" OCD_WAVE_SHR                             \
                      "v_add_f32 %[sy], %[y], %[sd]\n"                                                     \
                      "v_cndmask_b32_dpp %[x], %[sx], %[ex], vcc" OCD_WAVE_SHR)                            \
-                 : [x] "+&v"(x), [y] "+&v"(y), [sx] "=&v"(sx), [sy] "+&v"(sy)                               \
+                 : [x] "=&v"(x), [y] "=&v"(y), [sx] "=&v"(sx), [sy] "+&v"(sy)                            \
                  : [cd] "v"(cd), [sd] "v"(sd), [ex] "v"(ex), [ey] "v"(ey), [m] "s"(first_mask)           \
                  : "vcc");
-    OCD_CHAIN_ROUNDS(HT, OCD_STMT);
+    OCD_CHAIN_ROUNDS_M1(HT, OCD_STMT);
 #undef OCD_STMT
 }
 
@@ -163,21 +194,26 @@ __device__ __forceinline__ void seg_fwd_xy(float &x, float &y, float ex, float e
 //  cost more than the selects.  tools/microbench/dpp_exec.hip keeps the probe.)
 
 // ---- adjoint position recurrence (V_SEG):  Lx <- (qx + Lx) of the lane above, 0 in the segment's top lane ----
+// (Lx, Ly) are outputs: every lane starts at 0 (the first round adds the inline constant).
 template <int HT>
 __device__ __forceinline__ void seg_bwd_xy(float &Lx, float &Ly, float qx, float qy, unsigned long long last_mask)
 {
-    float ax, ay = qy + Ly;
+    float ax, ay = qy + 0.0f;
     const float zero = 0.0f;
 #define OCD_STMT(REP)                                                                                     \
     asm volatile("s_mov_b64 vcc, %[m]\n"                                                                  \
+                 "v_add_f32 %[ax], 0, %[qx]\n"                                                            \
+                 "v_cndmask_b32_dpp %[Ly], %[ay], %[z], vcc" OCD_WAVE_SHL                                 \
+                 "v_add_f32 %[ay], %[qy], %[Ly]\n"                                                        \
+                 "v_cndmask_b32_dpp %[Lx], %[ax], %[z], vcc" OCD_WAVE_SHL                                 \
                  REP("v_add_f32 %[ax], %[qx], %[Lx]\n"                                                    \
                      "v_cndmask_b32_dpp %[Ly], %[ay], %[z], vcc" OCD_WAVE_SHL                             \
                      "v_add_f32 %[ay], %[qy], %[Ly]\n"                                                    \
                      "v_cndmask_b32_dpp %[Lx], %[ax], %[z], vcc" OCD_WAVE_SHL)                            \
-                 : [Lx] "+&v"(Lx), [Ly] "+&v"(Ly), [ax] "=&v"(ax), [ay] "+&v"(ay)                           \
+                 : [Lx] "=&v"(Lx), [Ly] "=&v"(Ly), [ax] "=&v"(ax), [ay] "+&v"(ay)                        \
                  : [qx] "v"(qx), [qy] "v"(qy), [z] "v"(zero), [m] "s"(last_mask)                         \
                  : "vcc");
-    OCD_CHAIN_ROUNDS(HT, OCD_STMT);
+    OCD_CHAIN_ROUNDS_M1(HT, OCD_STMT);
 #undef OCD_STMT
 }
 
@@ -185,31 +221,34 @@ __device__ __forceinline__ void seg_bwd_xy(float &Lx, float &Ly, float qx, float
 //   Av = qv + Lv ; gA = gA1 + Av*dt ; gv2 = (-gA)*fr ; gv3 = (gv2*2)*v ; Lv <- ((gv1 + Av) + gv3) of the lane above
 //   Lth <- ((qth + Lth) + tau) of the lane above ; both 0 in the segment's top lane.
 // The heading chain runs half a round ahead (ltd is the NEXT round's (qth + Lth) + tau).
+// (Lv, Lth) are outputs: every lane starts at 0 (the first round adds the inline constant).
+#define OCD_SEG_LV(LV) "v_add_f32 %[av], " LV ", %[qv]\n"        \
+                       "v_add_f32 %[s], %[gv1], %[av]\n"         \
+                       "v_mul_f32 %[g], %[dt], %[av]\n"          \
+                       "v_add_f32 %[g], %[gA1], %[g]\n"          \
+                       "v_mul_f32_e64 %[g], -%[g], %[fr]\n"      \
+                       "v_add_f32 %[g], %[g], %[g]\n"            \
+                       "v_mul_f32 %[g], %[g], %[v]\n"            \
+                       "v_add_f32 %[s], %[s], %[g]\n"            \
+                       "v_cndmask_b32_dpp %[Lth], %[ltd], %[z], vcc" OCD_WAVE_SHL \
+                       "v_add_f32 %[ltd], %[qth], %[Lth]\n"      \
+                       "v_add_f32 %[ltd], %[ltd], %[tau]\n"      \
+                       "v_cndmask_b32_dpp %[Lv], %[s], %[z], vcc" OCD_WAVE_SHL
 template <int HT>
 __device__ __forceinline__ void seg_bwd_vth(float &Lv, float &Lth, float qv, float qth, float gA1, float gv1, float v,
                                             float tau, float fr, float dt, unsigned long long last_mask)
 {
-    float ltd = (qth + Lth) + tau, av, s, g;
+    float ltd = (qth + 0.0f) + tau, av, s, g;
     const float zero = 0.0f;
 #define OCD_STMT(REP)                                                                                     \
     asm volatile("s_mov_b64 vcc, %[m]\n"                                                                  \
-                 REP("v_add_f32 %[av], %[qv], %[Lv]\n"                                                    \
-                     "v_add_f32 %[s], %[gv1], %[av]\n"                                                    \
-                     "v_mul_f32 %[g], %[dt], %[av]\n"                                                     \
-                     "v_add_f32 %[g], %[gA1], %[g]\n"                                                     \
-                     "v_mul_f32_e64 %[g], -%[g], %[fr]\n"                                                 \
-                     "v_add_f32 %[g], %[g], %[g]\n"                                                       \
-                     "v_mul_f32 %[g], %[g], %[v]\n"                                                       \
-                     "v_add_f32 %[s], %[s], %[g]\n"                                                       \
-                     "v_cndmask_b32_dpp %[Lth], %[ltd], %[z], vcc" OCD_WAVE_SHL                           \
-                     "v_add_f32 %[ltd], %[qth], %[Lth]\n"                                                 \
-                     "v_add_f32 %[ltd], %[ltd], %[tau]\n"                                                 \
-                     "v_cndmask_b32_dpp %[Lv], %[s], %[z], vcc" OCD_WAVE_SHL)                             \
-                 : [Lv] "+&v"(Lv), [Lth] "+&v"(Lth), [ltd] "+&v"(ltd), [av] "=&v"(av), [s] "=&v"(s), [g] "=&v"(g) \
+                 OCD_SEG_LV("0")                                                                          \
+                 REP(OCD_SEG_LV("%[Lv]"))                                                                 \
+                 : [Lv] "=&v"(Lv), [Lth] "=&v"(Lth), [ltd] "+&v"(ltd), [av] "=&v"(av), [s] "=&v"(s), [g] "=&v"(g) \
                  : [qv] "v"(qv), [qth] "v"(qth), [gA1] "v"(gA1), [gv1] "v"(gv1), [v] "v"(v), [tau] "v"(tau), \
                    [z] "v"(zero), [fr] "s"(fr), [dt] "s"(dt), [m] "s"(last_mask)                          \
                  : "vcc");
-    OCD_CHAIN_ROUNDS(HT, OCD_STMT);
+    OCD_CHAIN_ROUNDS_M1(HT, OCD_STMT);
 #undef OCD_STMT
 }
 
