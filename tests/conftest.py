@@ -9,6 +9,11 @@ if ROOT not in sys.path:
 TESTS = os.path.dirname(os.path.abspath(__file__))
 if TESTS not in sys.path:
     sys.path.insert(0, TESTS)
+# the torch restatements of the reference (second opinion) live beside their fixture generators; only CPU tests
+# (test_oracle_vs_torch.py, test_oracle_kat.py) import them, no -m gpu test does
+GOLDEN = os.path.join(TESTS, "golden")
+if GOLDEN not in sys.path:
+    sys.path.append(GOLDEN)
 
 
 def pytest_configure(config):

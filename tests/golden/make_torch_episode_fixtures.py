@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Episode-level second-opinion fixtures: tests/golden/torch_episode_<case>.npz.
+
+Made in the BUILD container by tests/golden/torch_episode.py -- a float64 torch-autograd restatement of the
+reference's fitness loop (MPC_ORD.eval_weights -> eval_weights_for_init -> CarWorld.step -> PlannerCar ->
+NaivePlanner.generate_plan -> Car.step) written from the reference's Python with its scenario constants typed from
+the reference files.  Nothing of the product or of the C oracle is imported here: what the fixtures say about
+lane centres, scripted cars, plans, teleports, weight normalisation, scoring and sample order is independent of
+l4dc_mpc_ocd_amd.scenarios, oracle/ocd_oracle.c and the kernels.  (The reference itself cannot produce vectors
+here: TensorFlow is not installed)
+
+Cases (reference horizons: a float64 run is a meaningful target there):
+  finite_horizon_h5, local_opt_h5, replanning_h5, merging_h5      4 candidates x 8 inits (x 2 samples, replanning)
+  finite_horizon_h6                                               H = 6 -> n_iter = 200 (mpc_ord.py:192), 2 x 4
+  local_opt_h5_extra                                              extra_inits: 6 control initialisations, 2 x 4
+Candidates: the designer's weights (the "Iteration 0" evaluation, mpc_ord.py:39), the scenario's tuned weights
+(run_mpc_ord.py:25-42) where the reference has them, and designer + 0.05 * N(0, I) draws (run_mpc_ord.py:59).
+Inits: get_init_state(env_seed) of the scenario factories with env_seeds (seed * 1e6 + i) % 2**32
+(run_mpc_ord.py:80), seed 7; merging (no distribution in the reference): its init state plus typed offsets.
+
+Each file: init_states [N,4] f64, candidates [P,D] f64 and, from the float64 run, states / past / controls / chosen /
+margin / sample_reward / designer_reward / cost / removed / planner_w32 / designer_w32 (torch_episode.run), plus
+  stable [E] bool   the SAME episodes run by torch in float32 end within 2e-5 (relative return, absolute
+                    trajectory and controls) of the float64 run.  Decided by torch alone, not by the code under
+                    test: only those episodes are held to the 1e-4 tolerance -- where torch's own fp32 run leaves
+                    the fp64 one (an argmin between two initialisations decided in the last bits) no fp32
+                    implementation can be expected to follow it.
+  fp32_sample_reward [E]   torch's float32 returns (information).
+
+usage: python tests/golden/make_torch_episode_fixtures.py [case ...]      (deterministic; ~1 min per case)
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+import torch_episode as te  # noqa: E402
+
+ROOT_SEED = 7
+
+
+def inits_of(spec, n):
+    if spec["init_dist"] is None:                         # merging: typed offsets around merging.py:89's state
+        base = spec["default_init"]
+        offs = [(0.0, 0.0, 0.0), (-0.05, 0.03, 0.02), (0.04, -0.06, -0.04), (0.08, 0.05, 0.05), (-0.09, -0.02, 0.0),
+                (0.02, 0.09, -0.06), (-0.03, -0.09, 0.08), (0.06, 0.0, 0.03)]
+        return np.stack([base + np.array([dx, dy, dv, 0.0]) for dx, dy, dv in offs[:n]])
+    env_seeds = [(ROOT_SEED * 1000000 + i) % (2 ** 32) for i in range(n)]
+    return np.stack([te.init_state_of_seed(spec, s) for s in env_seeds])
+
+
+def candidates_of(spec, p, seed):
+    designer = np.asarray(te.designer_weights_of(spec), dtype=np.float64)
+    rows = [designer]
+    if spec["tuned_weights"] is not None and p > 1:
+        rows.append(np.asarray(spec["tuned_weights"], dtype=np.float64))
+    rng = np.random.RandomState(seed)
+    while len(rows) < p:
+        rows.append(designer + 0.05 * rng.standard_normal(designer.shape))
+    return np.stack(rows[:p])
+
+
+CASES = {
+    "finite_horizon_h5": (lambda: te.finite_horizon(5), 4, 8),
+    "local_opt_h5": (lambda: te.local_opt(5), 4, 8),
+    "replanning_h5": (lambda: te.replanning(5), 4, 8),
+    "merging_h5": (lambda: te.merging(5), 4, 8),
+    "finite_horizon_h6": (lambda: te.finite_horizon(6), 2, 4),
+    "local_opt_h5_extra": (lambda: te.local_opt(5, extra_inits=True), 2, 4),
+}
+
+
+def make(case):
+    factory, P, N = CASES[case]
+    spec = factory()
+    inits = inits_of(spec, N)
+    cands = candidates_of(spec, P, seed=100 + sorted(CASES).index(case))
+    t0 = time.time()
+    r64 = te.run(spec, inits, list(cands), dtype=torch.float64)
+    r32 = te.run(spec, inits, list(cands), dtype=torch.float32)
+    rel = np.abs(r32["sample_reward"] - r64["sample_reward"]) / np.maximum(1e-2, np.abs(r64["sample_reward"]))
+    E = rel.shape[0]
+    dtraj = np.abs(r32["states"] - r64["states"]).reshape(E, -1).max(axis=1)
+    dctrl = np.abs(r32["controls"] - r64["controls"]).reshape(E, -1).max(axis=1)
+    stable = (rel <= 2e-5) & (dtraj <= 2e-5) & (dctrl <= 2e-5) & np.all(r32["chosen"] == r64["chosen"], axis=1)
+    out = dict(init_states=inits, candidates=cands, stable=stable,
+               fp32_sample_reward=r32["sample_reward"].astype(np.float64),
+               horizon=np.int32(spec["horizon"]), n_iter=np.int32(spec["n_iter"]),
+               extra_inits=np.int32(spec["extra_inits"]), eval_horizon=np.int32(spec["eval_horizon"]),
+               num_samples=np.int32(spec["num_samples"]), scenario=np.array(spec["name"]))
+    out.update(r64)
+    path = os.path.join(HERE, f"torch_episode_{case}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{os.path.basename(path)}: {E} episodes, fp32-stable {int(stable.sum())}/{E}, returns "
+          f"{r64['sample_reward'].min():.4f} .. {r64['sample_reward'].max():.4f}, costs {np.round(r64['cost'], 4)}, "
+          f"chosen-init histogram {np.bincount(r64['chosen'].ravel()).tolist()}, removed {np.bincount(r64['removed']).tolist()}, "
+          f"{time.time() - t0:.0f} s", flush=True)
+
+
+def main():
+    torch.set_num_threads(1)
+    for case in (sys.argv[1:] or list(CASES)):
+        make(case)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Second-opinion fixtures for the GPU path: tests/golden/torch_<scenario>_h<H>.npz.
 
-Made in the BUILD container (torch-CPU autograd, float64) by tests/torch_restatement.py -- the restatement
+Made in the BUILD container (torch-CPU autograd, float64) by tests/golden/torch_restatement.py -- the restatement
 written from the reference's Python (merging.py:44-83, math_utils.py:28-31,87-95,166-178,
 simulation_utils.py:9-21, naive_planner.py:44-77,107-164), NOT from the C oracle and NOT from the kernels.
 The reference itself cannot produce vectors here (TensorFlow is not installed), so this is the
@@ -28,7 +28,7 @@ import sys
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 import torch_restatement as tr  # noqa: E402

@@ -1,0 +1,110 @@
+"""Shared checker of the EPISODE fixtures (tests/golden/torch_episode_*.npz, made by
+tests/golden/make_torch_episode_fixtures.py from a float64 torch restatement of the reference's fitness loop whose
+scenario constants are typed from the reference files): the same comparisons for the CPU oracle
+(tests/test_torch_episode_fixtures.py) and for the HIP path through ocd_rollout_episodes / ocd_plan_batch
+(tests/test_gpu_torch_episode_fixtures.py).  This module reads fixtures only -- the restatement itself stays beside
+its generator and is not imported by any test.
+
+What is compared, and how tightly (fp32 implementation against a float64 run of the reference's expressions):
+    scenario constants      designer weights EXACT (fp32 bits), planner weights of every candidate EXACT
+                            (the host-side normalisation chain), removed car per episode EXACT (reset toggle)
+    per-episode returns     1e-4 relative (the north_star tolerance) on the fp32-stable episodes
+    world trajectories      1e-4 absolute on the fp32-stable episodes (every car, every step, incl. scripted cars'
+                            real dynamics with their own friction, and the teleport)
+    applied controls        1e-4 absolute on the fp32-stable episodes
+    designer_reward, cost   1e-4 relative where all the episodes they sum are stable
+    chosen initialisation   EXACT wherever the float64 losses separate the best from the second-best by > 1e-3,
+                            at the fixture's own world states (ocd_plan_batch on `past`)
+"fp32-stable" is decided by the generator with torch alone (the same episodes in torch float32 stay within 2e-5 of
+the float64 run); the checker asserts that most episodes are stable and prints the fraction of ALL episodes within
+tolerance.
+"""
+import glob
+import os
+
+import numpy as np
+
+from l4dc_mpc_ocd_amd import scenarios
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def cases():
+    return sorted(os.path.basename(p)[len("torch_episode_"):-len(".npz")]
+                  for p in glob.glob(os.path.join(GOLDEN, "torch_episode_*.npz")))
+
+
+def load(case):
+    z = np.load(os.path.join(GOLDEN, f"torch_episode_{case}.npz"))
+    name = str(z["scenario"])
+    kw = dict(horizon=int(z["horizon"]))
+    if name in ("finite_horizon", "local_opt"):
+        kw["extra_inits"] = bool(z["extra_inits"])
+    scn = scenarios.SCENARIOS[name](**kw)             # the PRODUCT's descriptor: n_iter etc. are its own defaults
+    return scn, z
+
+
+def check(scn, z, rollout_fn, plan_fn=None):
+    """rollout_fn(init_states [N,4] f64, planner_w [P,D] f32) -> dict(returns [E], traj [E,T+1,C,4], ctrl [E,T,2]);
+    plan_fn(world_states [B,C,4] f32, weights [B,D] f32) -> best_init [B].  Returns a summary dict."""
+    d = scn.desc
+    inits, cands = z["init_states"], z["candidates"]
+    P, N, S, T = cands.shape[0], inits.shape[0], int(z["num_samples"]), int(z["eval_horizon"])
+    E = P * N * S
+    # --- the descriptor against constants typed from the reference ------------------------------------------------
+    assert (d.n_iter, d.episode_len, d.n_samples, d.horizon) == (int(z["n_iter"]), T, S, int(z["horizon"]))
+    assert d.n_ctrl_inits == (6 if int(z["extra_inits"]) else 3)
+    assert np.array_equal(scn.designer_weights, z["designer_w32"]), (scn.designer_weights, z["designer_w32"])
+    w32 = np.stack([scenarios.planner_weights_fp32(c) for c in cands])
+    assert np.array_equal(w32, z["planner_w32"])
+    assert np.array_equal(scenarios.planner_weights_fp32_batch(cands), z["planner_w32"])
+    removed = z["removed"]
+    if d.teleport_step > 0:
+        want = np.array([d.teleport_car[e % d.teleport_period] for e in range(E)], dtype=np.int32)
+        assert np.array_equal(want, removed), (want, removed)
+        assert set(removed.tolist()) == {1, 2}
+    else:
+        assert not removed.any()
+    # --- episodes -------------------------------------------------------------------------------------------------
+    out = rollout_fn(inits, w32)
+    ret, traj, ctrl = out["returns"].astype(np.float64), out["traj"].astype(np.float64), out["ctrl"].astype(np.float64)
+    assert ret.shape == (E,) and traj.shape == z["states"].shape and ctrl.shape == z["controls"].shape
+    stable = z["stable"]
+    assert stable.mean() >= 0.75, f"only {stable.sum()} of {E} episodes are fp32-stable in torch itself"
+    rerr = np.abs(ret - z["sample_reward"]) / np.maximum(1e-2, np.abs(z["sample_reward"]))
+    terr = np.abs(traj - z["states"]).reshape(E, -1).max(axis=1)
+    cerr = np.abs(ctrl - z["controls"]).reshape(E, -1).max(axis=1)
+    ok = (rerr <= 1e-4) & (terr <= 1e-4) & (cerr <= 1e-4)
+    assert ok[stable].all(), dict(returns=rerr[stable].max(), traj=terr[stable].max(), ctrl=cerr[stable].max(),
+                                  episodes=np.nonzero(stable & ~ok)[0])
+    # the state every step scores and plans from: after a teleport the removed car sits at (10, 0, 0, 0)
+    if d.teleport_step > 0:
+        t = d.teleport_step - 1
+        for e in range(E):
+            assert np.allclose(z["past"][e, t, removed[e]], (10., 0., 0., 0.)) and z["states"][e, t, removed[e], 0] < 1.0
+    # sums over samples (fp32 in the reference) and over inits (python floats), where every summand is stable
+    dr = ret.reshape(P, N, S).sum(axis=2)
+    st_pn = stable.reshape(P, N, S).all(axis=2)
+    derr = np.abs(dr - z["designer_reward"]) / np.maximum(1e-2, np.abs(z["designer_reward"]))
+    assert derr[st_pn].max() <= 1e-4
+    cost = -dr.sum(axis=1) / S
+    full = st_pn.all(axis=1)
+    if full.any():
+        assert (np.abs(cost - z["cost"])[full] <= 1e-4 * np.maximum(1.0, np.abs(z["cost"][full]))).all()
+    summary = dict(episodes=E, stable=int(stable.sum()), within_tol_all=float(ok.mean()),
+                   worst_return=float(rerr[stable].max()), worst_traj=float(terr[stable].max()),
+                   worst_ctrl=float(cerr[stable].max()))
+    # --- which control initialisation generate_plan keeps, at the fixture's own world states ----------------------
+    if plan_fn is not None:
+        losses_gap = z["margin"]                                    # [E, T] best-to-second gap of the float64 losses
+        clear = stable[:, None] & (losses_gap > 1e-3)
+        ee, tt = np.nonzero(clear)
+        assert len(ee) >= 0.5 * E * T, f"only {len(ee)} of {E * T} plans have a decided argmin"
+        ws = z["past"][ee, tt].astype(np.float32)
+        wrow = np.repeat(w32, N * S, axis=0)[ee]
+        got = np.asarray(plan_fn(ws, wrow)).astype(np.int32)
+        want = z["chosen"][ee, tt]
+        assert np.array_equal(got, want), f"{(got != want).sum()} of {len(got)} chosen initialisations differ"
+        summary["chosen_checked"] = int(len(ee))
+        summary["chosen_hist"] = np.bincount(want, minlength=d.n_ctrl_inits).tolist()
+    return summary

@@ -27,6 +27,8 @@ def fixtures():
     out = []
     for p in sorted(glob.glob(os.path.join(GOLDEN, "torch_*.npz"))):
         base = os.path.basename(p)[len("torch_"):-len(".npz")]
+        if base.startswith("episode_"):                 # whole-episode fixtures: tests/torch_episode_check.py
+            continue
         name, h = base.rsplit("_h", 1)
         out.append((name, int(h)))
     return out
