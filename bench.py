@@ -13,7 +13,15 @@ mpc_ord.py:128-137): `--config 4 --gpus 8 --scaling strong` / `--config 5 ...` a
 BASELINE.json states them.  `--emulate-rank R/W` runs, on ONE GPU, exactly the block rank R of a W-way strong
 split would run (config 4: 2 048 episodes at H=15, config 5: 4 096 at H=25, for W=8).
 Extra blocks of the same JSON line on rank 0 (single-GPU runs): BASELINE config 2 (pop 16 x 8 inits, 128
-episodes: the small-batch latency case) and the rank-0-of-8 shares of configs 4 and 5.
+episodes: the small-batch latency case), the rank-0-of-8 shares of configs 4 and 5, and the REFERENCE's own shape
+(`reference_h5`: finite_horizon H=5, pycma's default population 9 x 3 inits, K=3 -- what a user of
+`run_mpc_ord.py finite_horizon cmaes --n_inits 3` gets per generation; `reference_h6_extra`: H=6, n_iter 200,
+extra_inits K=6, the validation scripts' planner), each with its own CMA-ES generation wall-clock and a bounded CPU
+baseline beside it.
+`collective`: the one collective of a generation (all_gather_into_tensor of the fp32 returns over RCCL) timed by
+itself on device memory, with the ranks the process group saw -- at N=1 a one-rank RCCL group is created for it
+after the timed region (the headline stays the plain single-GPU step); `--force-collective` puts it INSIDE the timed
+step at N=1 as well.
 
 `python bench.py --gpus N` starts its N ranks itself (a torch.distributed.run child, spawned before
 anything touches the GPU) unless it already runs under a launcher (WORLD_SIZE set); the world size
@@ -102,7 +110,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(scn, inits, w32, budget_s=20.0):
+def cpu_baseline(scn, inits, w32, budget_s=16.0):
     """The CPU oracle (kind "port") timed on this host's cores on a bounded sample of the workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
@@ -170,6 +178,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse N>1 on a one-GPU box")
     ap.add_argument("--master-port", type=int, default=0)
+    ap.add_argument("--force-collective", action="store_true",
+                    help="N=1: create a one-rank RCCL group and run the all-gather of the returns inside every timed "
+                         "step, exactly as N ranks do")
     ap.add_argument("--plumbing-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -199,21 +210,60 @@ def main():
     dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     device = f"cuda:{dev_index}"
-    if world > 1:
+    def init_group():
+        """The process group of this run; a one-rank run rendezvous with itself on 127.0.0.1."""
+        kw = {}
+        if "MASTER_ADDR" not in os.environ or "WORLD_SIZE" not in os.environ:
+            port = args.master_port or (31000 + os.getpid() % 2000)
+            kw = dict(init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(device))
+            dist.init_process_group("nccl", device_id=torch.device(device), **kw)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", **kw)
         assert dist.get_world_size() == args.gpus
 
+    if world > 1 or args.force_collective:
+        init_group()
+
+    # the reference's own shapes (run_mpc_ord.py:19-44 with --n_inits 3; naive_planner.py:20,107-116; mpc_ord.py:192;
+    # pycma's default population for 7 weights is 9): not BASELINE configs, measured beside them
+    REFERENCE_SHAPES = {
+        "reference_h5": dict(scenario="finite_horizon", horizon=5, pop=9, n_inits=3, kwargs={}, seed=11,
+                             label="the reference's shape (run_mpc_ord.py finite_horizon cmaes --n_inits 3)"),
+        "reference_h6_extra": dict(scenario="finite_horizon", horizon=6, pop=9, n_inits=3, kwargs={"extra_inits": True},
+                                   seed=12, label="the reference's validation planner (H=6 -> n_iter 200, extra_inits)"),
+    }
+
     def workload(cfg_index, P):
-        cfg = scenarios.BASELINE_CONFIGS[cfg_index]
-        scn = scenarios.SCENARIOS[cfg["scenario"]](horizon=cfg["horizon"])
+        if cfg_index in REFERENCE_SHAPES:
+            cfg = REFERENCE_SHAPES[cfg_index]
+            scn = scenarios.SCENARIOS[cfg["scenario"]](horizon=cfg["horizon"], **cfg["kwargs"])
+            seed = cfg["seed"]
+        else:
+            cfg = scenarios.BASELINE_CONFIGS[cfg_index]
+            scn = scenarios.SCENARIOS[cfg["scenario"]](horizon=cfg["horizon"])
+            seed = cfg_index
         N, S = cfg["n_inits"], scn.desc.n_samples
-        inits = scn.init_dist.sample(N, seed=1000 + cfg_index)
-        cands = scn.candidate_weights(P, seed=2000 + cfg_index)
+        inits = scn.init_dist.sample(N, seed=1000 + seed)
+        cands = scn.candidate_weights(P, seed=2000 + seed)
         w32 = np.stack([scenarios.planner_weights_fp32(c) for c in cands])
         return cfg, scn, inits, w32, P, N, S
+
+    def time_all_gather(ret_dev, P, N, S, reps=20):
+        """Mean microseconds of the all-gather of the returns alone (device memory in, device memory out) and the
+        ranks the group saw.  Every rank calls it at the same point."""
+        for _ in range(3):
+            sharding.gather_returns(ret_dev, P, N, S, force=True)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            sharding.gather_returns(ret_dev, P, N, S, force=True)
+        torch.cuda.synchronize()
+        us = (time.perf_counter() - t0) / reps * 1e6
+        return {"backend": ("nccl (RCCL)" if dist.get_backend() == "nccl" else dist.get_backend()),
+                "ranks_seen": dist.get_world_size(), "all_gather_us": us,
+                "bytes_per_rank": int(ret_dev.numel() * 4), "calls_timed": reps}
 
     def timed_generations(cfg_index, P, ranks, rnk, steps, warmup, collective=True):
         """(seconds for `steps` generations, kernel ms, fitness, context) of one workload: the population P split
@@ -225,7 +275,7 @@ def main():
         w_dev = torch.as_tensor(w32).to(device)                 # inputs resident in HBM before timing
         e0, e1 = sharding.episode_range(P, N, S, ranks, rnk)
         ret_dev = torch.empty(e1 - e0, dtype=torch.float32, device=device)
-        sharded = ranks > 1 and collective
+        sharded = (ranks > 1 or args.force_collective) and collective and dist.is_initialized()
         lo, hi = sharding.candidate_block(P, ranks, rnk)
         host = torch.empty(P * N * S, dtype=torch.float32).pin_memory()     # one pinned buffer, one event per step
         host_np = host.numpy()
@@ -241,7 +291,7 @@ def main():
                 done.record()
                 done.synchronize()
                 return sharding.fitness_from_returns(host_np[:n_out], hi - lo, N, S)
-            src = sharding.gather_returns(ret_dev, P, N, S)
+            src = sharding.gather_returns(ret_dev, P, N, S, force=args.force_collective)
             if src.is_cuda:
                 host.copy_(src, non_blocking=True)
                 done.record()
@@ -271,9 +321,16 @@ def main():
             tt = torch.tensor([dt], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
-        # dominant kernel: average launch duration from HIP events on the launch stream
-        kern_ms = eng.time_rollout(init_dev, w_dev, e0, e1, ret_dev, reps=max(3, min(steps, 20)))
-        return dt, kern_ms, fit, (cfg, scn, inits, w32, P, N, S, e1 - e0, eng.last_launch())
+        # dominant kernel: average launch duration from HIP events on the launch stream, writing where the timed
+        # generations write (one process: the pinned host buffer the kernel stores its returns into directly;
+        # sharded: the device buffer the all-gather reads) -- kernel_ms and ms_per_step describe the same launch
+        kern_ms = eng.time_rollout(init_dev, w_dev, e0, e1, ret_dev if sharded else host[:n_out],
+                                   reps=max(3, min(steps, 20)))
+        launch = dict(eng.last_launch(), returns_written_to="device memory" if sharded else "pinned host memory (zero-copy)")
+        coll = None
+        if sharded:                                                # the generation's one collective by itself
+            coll = time_all_gather(ret_dev, P, N, S)
+        return dt, kern_ms, fit, (cfg, scn, inits, w32, P, N, S, e1 - e0, launch, coll)
 
     def share_block(cfg_index, r, w, steps, warmup):
         """Rank r's block of a w-way strong split of BASELINE config cfg_index, on this GPU alone."""
@@ -282,10 +339,40 @@ def main():
         b = block(cfg_index, dt_, k_, ctx_, steps, per_gpu_only=True)
         b["emulated_rank"] = f"{r}/{w}"
         b["generation_cost_checksum"] = float(np.sum(fit_))
+        if not args.no_cpu_baseline:                                # this rank's candidate block on the host's cores
+            lo_, hi_ = sharding.candidate_block(P, w, r)
+            b["cpu_baseline"] = cpu_baseline(ctx_[1], ctx_[2], ctx_[3][lo_:hi_], budget_s=2.0)
         return b
 
+    def cma_generations(cfg, popsize, reduce_over_ranks, gens=48):
+        """ask -> host normalisation -> launch -> (gather) -> returns in pinned host memory -> float64 reduction ->
+        tell, through MPC_ORD.optimize_cmaes (mpc_ord.py:33-45); every rank runs the same deterministic strategy.
+        The first generations run on a GPU whose clocks are still rising (the kernel itself takes 1.73 -> 1.61 ms
+        over the first ten generations of a cold process): the last 32 of `gens` are timed, like kernel_ms after its
+        warm-up."""
+        from l4dc_mpc_ocd_amd.interact_drive.experiments import run_mpc_ord as rmo
+        m = rmo.make_mpc_ord(cfg["scenario"], horizon=cfg["horizon"], n_inits=cfg["n_inits"], seed=1,
+                             **cfg.get("kwargs", {}))
+        m.optimize_cmaes(seed=1, sigma0=0.05, popsize=popsize, maxiter=gens)
+        gs = np.array(m.generation_seconds[-32:]) * 1e3
+        fs = np.array(m.fitness_seconds[-32:]) * 1e3            # eval_population alone (no ask / tell)
+        med = float(np.median(gs))
+        if reduce_over_ranks and world > 1:
+            tt = torch.tensor([med], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            med = float(tt.item())
+        return {"cma_generation_ms": med, "fitness_ms": float(np.median(fs)),
+                "generations_run": int(len(m.generation_seconds)), "generations_timed": int(len(gs)),
+                "popsize": int(m.es.lam), "n_inits": cfg["n_inits"], "stop_reason": {k: float(v) for k, v in m.stop_reason.items()},
+                "n_nonfinite": int(sum(m.n_nonfinite)), "n_resampled": int(m.n_resampled),
+                "host_split_ms": m.host_split_ms(),
+                "path": "MPC_ORD.optimize_cmaes: ask (native, csrc/ocd_cma.c), host normalisation into pinned memory "
+                        "the kernel reads, launch, (gather,) returns written to / copied into pinned host memory, "
+                        "float64 reduction (native), NaN costs redrawn as pycma does, tell (native), pycma's "
+                        "termination rules; own CMA-ES, pycma is not installed"}
+
     def block(cfg_index, dt, kern_ms, ctx, steps, per_gpu_only=False):
-        cfg, scn, inits, w32, P, N, S, n_local, launch = ctx
+        cfg, scn, inits, w32, P, N, S, n_local, launch, _coll = ctx
         kernel_name = ("ocd::mpc_chunk_kernel" if launch["scan_mode"] == 4 else "ocd::mpc_kernel") + \
             f" ({launch['mapping']}" + (f", {launch['chunk']} steps per lane" if launch["chunk"] else "") + \
             f", {launch['trajectories_per_wavefront']} trajectories per wavefront, {launch['workgroups']} workgroups x " \
@@ -297,7 +384,8 @@ def main():
         ach_gbs = n_local * nbytes / (kern_ms * 1e-3) / 1e9
         ach_tf = n_local * flops / (kern_ms * 1e-3) / 1e12
         n_split = max(1, round(P * N * S / max(n_local, 1)))
-        pmc = pmc_record(f"cfg{cfg_index}_share{n_split}" if per_gpu_only else f"cfg{cfg_index}", n_local)
+        pmc = pmc_record(f"cfg{cfg_index}_share{n_split}" if per_gpu_only else
+                         (cfg_index if isinstance(cfg_index, str) else f"cfg{cfg_index}"), n_local)
         traffic = (pmc["fetch_kib"] + pmc["write_kib"]) * 1024.0 if pmc else None
         profiled = None
         valu = {"achieved": ach_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / VALU_PEAK_TFLOPS,
@@ -313,8 +401,9 @@ def main():
                 profiled["wait_fraction"] = pmc["sq_wait_any"] / pmc["sq_wave_cycles"]
                 profiled["valu_instructions_per_launch"] = pmc["sq_insts_valu"]
         pop_text = (f"pop {P} split over {n_split} ranks" if n_split > 1 else f"pop {P}")
+        what = cfg["label"] if isinstance(cfg_index, str) else f"BASELINE config {cfg_index}"
         out = {
-            "workload": f"BASELINE config {cfg_index}: {cfg['scenario']}, CMA-ES {pop_text} x {N} inits x "
+            "workload": f"{what}: {cfg['scenario']}, CMA-ES {pop_text} x {N} inits x "
                         f"{S} samples, planning horizon H={d.horizon}, n_iter={d.n_iter}, K={d.n_ctrl_inits} control "
                         f"inits, episode length T={d.episode_len}",
             "episodes_per_generation": P * N * S, "episodes_per_gpu": n_local,
@@ -341,47 +430,40 @@ def main():
         if P_total < world:
             raise SystemExit(f"bench.py: population {P_total} < {world} ranks")
         dt, kern_ms, fit, ctx = timed_generations(args.config, P_total, world, rank, args.steps, args.warmup)
+    coll = ctx[9]
 
     # ---- extras: config 2 (small-batch latency) on rank 0, CMA-ES generation wall-clock on all ranks ----
     extra2 = None
     shares = {}
+    reference_blocks = {}
     cma = None
     if not args.no_extras:
         if rank == 0 and args.config != 2:
             dt2, k2, _, ctx2 = timed_generations(2, scenarios.BASELINE_CONFIGS[2]["pop"], 1, 0, args.steps, args.warmup)
             extra2 = block(2, dt2, k2, ctx2, args.steps)
+            if world == 1 and not args.no_cpu_baseline:
+                extra2["cpu_baseline"] = cpu_baseline(ctx2[1], ctx2[2], ctx2[3], budget_s=2.0)
         if rank == 0 and world == 1 and not emulate:
             # what ONE of 8 GPUs runs of BASELINE configs 4 / 5 (strong split): the shapes the 8-GPU lines are made of
             n_sh = max(3, min(args.steps, 20))
             shares = {f"config{c}_share8": share_block(c, 0, 8, n_sh, 2) for c in (4, 5)}
-        # ask -> host normalisation -> H2D -> launch -> (gather) -> D2H -> float64 reduction -> tell, through
-        # MPC_ORD.optimize_cmaes (mpc_ord.py:33-45); every rank runs the same deterministic strategy
-        from l4dc_mpc_ocd_amd.interact_drive.experiments import run_mpc_ord as rmo
         cfg = scenarios.BASELINE_CONFIGS[args.config]
-        m = rmo.make_mpc_ord(cfg["scenario"], horizon=cfg["horizon"], n_inits=cfg["n_inits"], seed=1)
-        gens = 48
         cma_pop = cfg["pop"] * world if args.scaling == "weak" else cfg["pop"]
-        m.optimize_cmaes(seed=1, sigma0=0.05, popsize=cma_pop, maxiter=gens)
-        # the first generations run on a GPU whose clocks are still rising (the kernel itself takes 1.73 -> 1.61 ms over
-        # the first ten generations of a cold process): the last 32 are timed, like kernel_ms after its warm-up
-        gs = np.array(m.generation_seconds[-32:]) * 1e3
-        fs = np.array(m.fitness_seconds[-32:]) * 1e3            # eval_population alone (no ask / tell)
-        if world > 1:
-            tt = torch.tensor([float(np.median(gs))], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            med = float(tt.item())
-        else:
-            med = float(np.median(gs))
-        cma = {"cma_generation_ms": med, "fitness_ms": float(np.median(fs)), "generations_timed": int(len(gs)),
-               "popsize": cma_pop,
-               "host_split_ms": m.host_split_ms() if hasattr(m, "host_split_ms") else None,
-               "n_inits": cfg["n_inits"], "path": "MPC_ORD.optimize_cmaes: ask (native, csrc/ocd_cma.c), host normalisation into pinned memory "
-                                                   "the kernel reads, launch, (gather,) returns written to / copied into pinned "
-                                                   "host memory, float64 reduction (native), tell (native); own CMA-ES, pycma is not "
-                                                   "installed"}
+        cma = cma_generations(cfg, cma_pop, reduce_over_ranks=True)
+        if rank == 0 and world == 1 and not emulate:
+            n_rf = max(3, min(args.steps, 20))
+            for name, spec in REFERENCE_SHAPES.items():
+                dt_r, k_r, fit_r, ctx_r = timed_generations(name, spec["pop"], 1, 0, n_rf, 2, collective=False)
+                b = block(name, dt_r, k_r, ctx_r, n_rf)
+                b["generation_cost_checksum"] = float(np.sum(fit_r))
+                c = cma_generations(spec, None, reduce_over_ranks=False)      # popsize None: pycma's default 9
+                b["cma_generation_ms"], b["cma"] = c["cma_generation_ms"], c
+                if not args.no_cpu_baseline:
+                    b["cpu_baseline"] = cpu_baseline(ctx_r[1], ctx_r[2], ctx_r[3], budget_s=2.0)
+                reference_blocks[name] = b
 
     if rank == 0:
-        cfg, scn, inits, w32, P, N, S, n_local, _ = ctx
+        cfg, scn, inits, w32, P, N, S, n_local, _, _ = ctx
         d = scn.desc
         hb = block(args.config, dt, kern_ms, ctx, args.steps, per_gpu_only=bool(emulate))
         out = {
@@ -415,10 +497,27 @@ def main():
         if extra2:
             out["config2"] = extra2
         out.update(shares)
+        out.update(reference_blocks)
         if world == 1 and not args.no_cpu_baseline and not emulate:
             out["cpu_baseline"] = cpu_baseline(scn, inits, w32)
+    # ---- the generation's one collective, by itself: RCCL all-gather of the returns on device memory ----
+    if coll is None and world == 1 and not emulate and not args.no_extras:
+        # a one-GPU run has no collective in its timed step; run the N-rank code path once anyway (one-rank RCCL
+        # group, sharding.gather_returns on device tensors) so that it has executed before any multi-GPU run
+        try:
+            if not dist.is_initialized():
+                init_group()
+            n_ret = ctx[7]
+            coll = time_all_gather(torch.zeros(n_ret, dtype=torch.float32, device=device), ctx[4], ctx[5], ctx[6])
+            coll["in_timed_step"] = False
+        except Exception as exc:                                  # the headline must not depend on it
+            coll = {"error": f"{type(exc).__name__}: {exc}"[:300], "in_timed_step": False}
+    elif coll is not None:
+        coll["in_timed_step"] = True
+    if rank == 0:
+        out["collective"] = coll
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

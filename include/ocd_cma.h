@@ -23,6 +23,7 @@ extern "C" {
 #endif
 
 #define OCD_CMA_MAX_DIM 64
+#define OCD_CMA_ABI_VERSION 2      /* 2: ocd_cma_tell returns the non-finite count; resample, stop_state, abi_version */
 
 typedef struct ocd_cma ocd_cma;
 
@@ -32,18 +33,29 @@ typedef struct ocd_cma ocd_cma;
 int32_t ocd_cma_create(int32_t n, const double *x0, double sigma0, int32_t popsize, uint32_t seed, ocd_cma **out);
 void ocd_cma_destroy(ocd_cma *es);
 int32_t ocd_cma_popsize(const ocd_cma *es);
+/* OCD_CMA_ABI_VERSION of the built library: the binding refuses a stale libocd_cma.so. */
+int32_t ocd_cma_abi_version(void);
 
 /* Draw the normal deviates of the next population ahead of time (they do not depend on the state of the search):
  * for callers with something to wait for -- the running episode kernel.  Optional; the stream is the same. */
 int32_t ocd_cma_prepare(ocd_cma *es);
 /* X [lambda, n] <- the next population: mean + sigma * C^(1/2) z (symmetric square root). */
 int32_t ocd_cma_ask(ocd_cma *es, double *X);
-/* The update of one generation from the population last asked for and its costs fitness [lambda] (lower is better). */
+/* Row k of X <- one more candidate for slot k of the population last asked for (n fresh deviates): what pycma's
+ * ask_and_eval does with a candidate whose cost came back NaN (rejection sampling around mpc_ord.py:41). */
+int32_t ocd_cma_resample(ocd_cma *es, int32_t k, double *X);
+/* The update of one generation from the population last asked for (X must be what ask / resample wrote: the update
+ * uses the steps behind those rows) and its costs fitness [lambda] (lower is better).  Costs are ranked with NaN LAST
+ * (numpy's argsort order; +inf just before); returns the number of non-finite costs (>= 0), or -1 on bad arguments. */
 int32_t ocd_cma_tell(ocd_cma *es, const double *X, const double *fitness);
 /* Any of the outputs may be NULL: mean [n], sigma, C [n, n], best_x [n], best_f, generations, evaluations,
  * max_axis = the largest sqrt-eigenvalue of C (the stopping rule sigma * max_axis < tolx). */
 int32_t ocd_cma_state(const ocd_cma *es, double *mean, double *sigma, double *C, double *best_x, double *best_f,
                       int64_t *gen, int64_t *counteval, double *max_axis);
+
+/* What the termination rules read after a tell (see ocd_cma.c): sigma, axis lengths, counters, the best / median /
+ * worst cost of the population last told, non-finite counts, sigma * max sqrt(C_ii), sigma * max |pc_i|, min sqrt(C_ii). */
+int32_t ocd_cma_stop_state(const ocd_cma *es, double out[13]);
 
 /* returns [P, N, S] fp32 sample rewards -> cost_out [P]: samples summed sequentially in fp32 (TensorFlow scalars,
  * mpc_ord.py:102), inits sequentially in float64 (mpc_ord.py:126,137), / S, negated (mpc_ord.py:139,151). */

@@ -28,8 +28,10 @@ struct ocd_cma {
     int n, lam, mu;
     double sigma, mueff, cc, cs, c1, cmu, damps, chiN;
     double *mean, *weights, *pc, *ps, *C, *B, *D, *sqrtC, *invsqrtC, *y, *best_x, *tmp, *work;
-    double best_f, max_d;
-    int64_t gen, counteval;
+    double best_f, max_d, min_d;
+    double fit_best, fit_median, fit_worst;   /* of the population last told (non-finite costs excluded from best / worst) */
+    int64_t gen, counteval, nonfinite_total;
+    int last_nonfinite;
     int *order;
     double *z;                /* [lam, n] the normal deviates of the NEXT population, drawn ahead by ocd_cma_prepare */
     int z_ready;
@@ -148,9 +150,11 @@ static void decompose(ocd_cma *es)
     memcpy(es->work, es->C, sizeof(double) * n * n);
     jacobi_eigh(n, es->work, es->D, es->B);
     es->max_d = 0.0;
+    es->min_d = INFINITY;
     for (int i = 0; i < n; ++i) {
         es->D[i] = sqrt(es->D[i] > 1e-20 ? es->D[i] : 1e-20);
         if (es->D[i] > es->max_d) es->max_d = es->D[i];
+        if (es->D[i] < es->min_d) es->min_d = es->D[i];
     }
     for (int i = 0; i < n; ++i)
         for (int j = i; j < n; ++j) {
@@ -206,8 +210,9 @@ int32_t ocd_cma_create(int32_t n, const double *x0, double sigma0, int32_t popsi
         es->C[i * n + i] = es->B[i * n + i] = es->sqrtC[i * n + i] = es->invsqrtC[i * n + i] = 1.0;
         es->D[i] = 1.0;
     }
-    es->max_d = 1.0;
+    es->max_d = es->min_d = 1.0;
     es->best_f = INFINITY;
+    es->fit_best = es->fit_median = es->fit_worst = NAN;
     mt_seed(es, seed);
     *out = es;
     return 0;
@@ -222,6 +227,7 @@ void ocd_cma_destroy(ocd_cma *es)
 }
 
 int32_t ocd_cma_popsize(const ocd_cma *es) { return es ? es->lam : -1; }
+int32_t ocd_cma_abi_version(void) { return OCD_CMA_ABI_VERSION; }
 
 /* The deviates do not depend on the state of the search: a caller with something to wait for (the running episode
  * kernel) draws the next population's while it waits; ask() draws them itself otherwise.  Same stream either way. */
@@ -255,15 +261,55 @@ int32_t ocd_cma_ask(ocd_cma *es, double *X)
     return 0;
 }
 
+/* One more candidate for row k of the population last asked for: pycma's ask_and_eval draws a replacement for a
+ * candidate whose cost is NaN and evaluates that instead (rejection sampling, cma.evolution_strategy.fmin2 as called
+ * from mpc_ord.py:41).  n fresh deviates from the stream (after any block ocd_cma_prepare has drawn ahead). */
+int32_t ocd_cma_resample(ocd_cma *es, int32_t k, double *X)
+{
+    if (!es || !X || k < 0 || k >= es->lam) return -1;
+    const int n = es->n;
+    double *z = es->work;                        /* scratch: decompose() is not running */
+    for (int i = 0; i < n; ++i) z[i] = gauss(es);
+    double *y = es->y + (size_t)k * n;
+    for (int i = 0; i < n; ++i) {
+        double a = 0.0;
+        for (int j = 0; j < n; ++j) a += es->sqrtC[i * n + j] * z[j];
+        y[i] = a;
+        X[(size_t)k * n + i] = es->mean[i] + es->sigma * a;
+    }
+    return 0;
+}
+
+/* Sort key of a cost: NaN ranks after everything else (numpy's argsort order, which the numpy twin uses; a raw `>`
+ * comparison would leave a NaN wherever it was inserted and stop smaller costs from passing it). */
+static inline int cost_after(double a, double b)       /* a strictly after b */
+{
+    if (isnan(a)) return !isnan(b);
+    if (isnan(b)) return 0;
+    return a > b;
+}
+
 int32_t ocd_cma_tell(ocd_cma *es, const double *X, const double *fitness)
 {
     if (!es || !X || !fitness) return -1;
     const int n = es->n, lam = es->lam, mu = es->mu;
-    /* stable argsort of the fitness (insertion sort: lam is small) */
+    /* stable argsort of the fitness, NaN last (insertion sort: lam is small) */
+    int nonfinite = 0, n_nan = 0;
     for (int k = 0; k < lam; ++k) {
         int j = k;
-        while (j > 0 && fitness[es->order[j - 1]] > fitness[k]) { es->order[j] = es->order[j - 1]; --j; }
+        while (j > 0 && cost_after(fitness[es->order[j - 1]], fitness[k])) { es->order[j] = es->order[j - 1]; --j; }
         es->order[j] = k;
+        if (!isfinite(fitness[k])) ++nonfinite;
+        if (isnan(fitness[k])) ++n_nan;
+    }
+    es->last_nonfinite = nonfinite;
+    es->nonfinite_total += nonfinite;
+    {   /* statistics of this population for the termination rules: best, median (numpy's: NaN if any), worst non-NaN */
+        const int m = lam - n_nan;
+        es->fit_best = m > 0 ? fitness[es->order[0]] : NAN;
+        es->fit_worst = m > 0 ? fitness[es->order[m - 1]] : NAN;
+        es->fit_median = n_nan ? NAN : ((lam & 1) ? fitness[es->order[lam / 2]]
+                                                  : 0.5 * (fitness[es->order[lam / 2 - 1]] + fitness[es->order[lam / 2]]));
     }
     const int b = es->order[0];
     if (fitness[b] < es->best_f) {
@@ -304,7 +350,7 @@ int32_t ocd_cma_tell(ocd_cma *es, const double *X, const double *fitness)
     es->sigma *= exp((es->cs / es->damps) * (ps_norm / es->chiN - 1));
     decompose(es);
     es->gen += 1;
-    return 0;
+    return nonfinite;
 }
 
 int32_t ocd_cma_state(const ocd_cma *es, double *mean, double *sigma, double *C, double *best_x, double *best_f,
@@ -320,6 +366,29 @@ int32_t ocd_cma_state(const ocd_cma *es, double *mean, double *sigma, double *C,
     if (gen) *gen = es->gen;
     if (counteval) *counteval = es->counteval;
     if (max_axis) *max_axis = es->max_d;
+    return 0;
+}
+
+/* The numbers the termination rules of reward_design/cmaes.py read after a tell, in one call:
+ * out[0..4] = sigma, largest and smallest sqrt-eigenvalue of C, generations, evaluations;
+ * out[5..7] = best / median / worst (NaN excluded from best and worst) cost of the population last told;
+ * out[8..9] = non-finite costs in that population / in all populations told so far;
+ * out[10] = max_i sigma * sqrt(C_ii), out[11] = max_i sigma * |pc_i| (pycma's tolx reads both), out[12] = min_i sqrt(C_ii). */
+int32_t ocd_cma_stop_state(const ocd_cma *es, double out[13])
+{
+    if (!es || !out) return -1;
+    const int n = es->n;
+    double dmax = 0.0, dmin = INFINITY, pmax = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const double d = sqrt(es->C[i * n + i]), p = fabs(es->pc[i]);
+        if (d > dmax) dmax = d;
+        if (d < dmin) dmin = d;
+        if (p > pmax) pmax = p;
+    }
+    out[0] = es->sigma; out[1] = es->max_d; out[2] = es->min_d; out[3] = (double)es->gen; out[4] = (double)es->counteval;
+    out[5] = es->fit_best; out[6] = es->fit_median; out[7] = es->fit_worst;
+    out[8] = (double)es->last_nonfinite; out[9] = (double)es->nonfinite_total;
+    out[10] = es->sigma * dmax; out[11] = es->sigma * pmax; out[12] = dmin;
     return 0;
 }
 

@@ -36,12 +36,13 @@ envs = {
 }
 
 
-def make_mpc_ord(scenario, horizon=None, n_inits=1, seed=1, save_path=None):
+def make_mpc_ord(scenario, horizon=None, n_inits=1, seed=1, save_path=None, **scenario_kwargs):
     """MPC_ORD over `scenario` at an arbitrary planning horizon with `n_inits` synthetic init states
-    (scenarios.InitDistribution.sample: the seeded inverse-CDF sampler of the benchmark configs)."""
+    (scenarios.InitDistribution.sample: the seeded inverse-CDF sampler of the benchmark configs);
+    scenario_kwargs go to the scenario factory (e.g. extra_inits=True)."""
     from ._build import world_from_scenario
     from .replanning_world import ReplanningCarWorld
-    scn = scenarios.SCENARIOS[scenario](**({} if horizon is None else {"horizon": horizon}))
+    scn = scenarios.SCENARIOS[scenario](**dict(scenario_kwargs, **({} if horizon is None else {"horizon": horizon})))
     init_states = list(scn.init_dist.sample(n_inits, seed=seed))
     world_cls = ReplanningCarWorld if scenario == "replanning" else None
     car, _, world = world_from_scenario(scn, init_states[0], debug=True, world_cls=world_cls)
@@ -99,9 +100,11 @@ def main(argv=None):
     results = []
     for group in init_states_groups:
         mpc_ord, best = run_opt(env, group, args, optimization_seed)
-        top = max(mpc_ord.history, key=lambda a: a[1])
+        finite = [h for h in mpc_ord.history if np.isfinite(h[1])]
+        top = max(finite or mpc_ord.history, key=lambda a: a[1])
         print(f'evaluations {len(mpc_ord.history)}  designer-weights reward {mpc_ord.history[0][1]:.6f}  '
-              f'best reward {top[1]:.6f}  best weights {fmt(top[0])}')
+              f'best reward {top[1]:.6f}  best weights {fmt(top[0])}  non-finite costs {sum(mpc_ord.n_nonfinite)}'
+              + (f'  stopped on {getattr(mpc_ord, "stop_reason", None)}' if args.optimizer == 'cmaes' else ''))
         if getattr(mpc_ord, "generation_seconds", None):
             gs = mpc_ord.generation_seconds
             print(f'CMA-ES generations {len(gs)}  median generation wall-clock {np.median(gs) * 1e3:.2f} ms')

@@ -13,14 +13,122 @@ Two implementations of the same algorithm:
   CMAES        numpy; the twin the tests compare the native one with (same normal deviates bit for bit, same
                candidates to rounding: both sample m + sigma * C^(1/2) z with the SYMMETRIC root, which does not
                depend on the order or sign of the eigenvectors LAPACK / the native Jacobi sweep return).
+
+Non-finite costs (both twins, identically): a population is ranked with NaN LAST (numpy's argsort order, +inf just
+before it) and tell() returns how many costs were not finite; resample(k) draws a replacement for slot k the way
+pycma's ask_and_eval does for a candidate whose cost came back NaN (rejection sampling); MPC_ORD.optimize_cmaes
+uses both.  Termination (`stop()`, one implementation shared by the twins) follows pycma's documented default
+options -- maxiter = 100 + 150 (N + 3)^2 / sqrt(popsize), tolfun 1e-11, tolfunhist 1e-12, tolx 1e-11,
+tolstagnation = 100 + 100 N^1.5 / popsize, tolconditioncov 1e14, tolfacupx 1e3, tolupsigma 1e20, flat fitness --
+restated from pycma's option table (pycma itself is absent: "parity unpinned").
 """
 import ctypes as C
+import math
 import os
 
 import numpy as np
 
 
-class CMAES:
+class _Termination:
+    """pycma's termination rules on the numbers both twins expose through _stop_state().
+
+    Options and defaults as pycma's CMAOptions documents them (cma.evolution_strategy, the dependency behind
+    mpc_ord.py:41; not installed here, restated):
+        maxiter          100 + 150 * (N + 3) ** 2 // popsize ** 0.5
+        maxfevals        inf
+        tolfun           1e-11   range of the current population's costs AND of the recent best costs below it
+        tolfunhist       1e-12   range of the recent best costs (at least 10 generations of them)
+        tolx             1e-11   sigma * sqrt(C_ii) and sigma * |pc_i| below it in every coordinate
+        tolfacupx        1e3     sigma * sqrt(C_ii) grew beyond tolfacupx * sigma0 (initial step far too small)
+        tolconditioncov  1e14    condition number of C
+        tolupsigma       1e20    sigma / sigma0 above tolupsigma * the longest axis of C ("creeping")
+        tolstagnation    100 + 100 * N ** 1.5 / popsize   generations without progress of the median / best costs
+        tolflatfitness   1       generations in a row whose best and median cost coincide
+    The "recent best costs" are those of the last 10 + 30 N / popsize generations, as in pycma.  stop() returns
+    pycma's dict of the satisfied conditions ({} = go on), e.g. {'tolx': 1e-11}."""
+
+    def _init_termination(self, sigma0):
+        n, lam = self.n, self.lam
+        self.sigma0 = float(sigma0)
+        self.opts = dict(maxiter=100 + 150 * (n + 3) ** 2 // lam ** 0.5, maxfevals=np.inf, tolfun=1e-11,
+                         tolfunhist=1e-12, tolx=1e-11, tolfacupx=1e3, tolconditioncov=1e14, tolupsigma=1e20,
+                         tolstagnation=int(100 + 100 * n ** 1.5 / lam), tolflatfitness=1)
+        self._hist = []                 # best cost of the last 10 + 30 N / popsize generations, newest first
+        self._hist_len = 10 + 30 * n / lam
+        self._histbest, self._histmedian = [], []
+        self._flat = 0
+        self._last_pop_range = np.inf
+        self.nonfinite_total = 0
+        self.last_nonfinite = 0
+
+    def _record(self, best, median, worst, nonfinite):
+        """After every tell: this population's best / median / worst cost (NaN kept out of best and worst)."""
+        self.last_nonfinite = int(nonfinite)
+        self.nonfinite_total += int(nonfinite)
+        self._hist.insert(0, best)
+        if len(self._hist) > self._hist_len:
+            self._hist.pop()
+        self._histbest.append(best)                               # oldest first (pycma keeps them newest first)
+        self._histmedian.append(median)
+        if len(self._histbest) > 20000:
+            del self._histbest[0], self._histmedian[0]
+        self._last_pop_range = worst - best if math.isfinite(worst) and math.isfinite(best) else np.inf
+        self._flat = self._flat + 1 if best == median else 0
+
+    def stop(self, tolfun=None, tolx=None, maxiter=None, last_fitness=None, **overrides):
+        """{} while the search should go on, else the satisfied conditions.  Keyword arguments override the
+        defaults for this call (maxiter=None keeps pycma's default cap; last_fitness is accepted for older
+        callers and ignored: the population's costs are recorded by tell())."""
+        o = dict(self.opts)
+        for k, v in dict(tolfun=tolfun, tolx=tolx, maxiter=maxiter, **overrides).items():
+            if v is not None:
+                if k not in o:
+                    raise TypeError(f"unknown termination option {k!r}")
+                o[k] = v
+        st = self._stop_state()
+        out = {}
+        if st["gen"] >= o["maxiter"]:
+            out["maxiter"] = o["maxiter"]
+        if st["counteval"] >= o["maxfevals"]:
+            out["maxfevals"] = o["maxfevals"]
+        if st["gen"] == 0:
+            return out
+        h = [v for v in self._hist if math.isfinite(v)]
+        hist_range = (max(h) - min(h)) if h else np.inf
+        if self._last_pop_range < o["tolfun"] and hist_range < o["tolfun"]:
+            out["tolfun"] = o["tolfun"]
+        if len(self._hist) > 9 and hist_range < o["tolfunhist"]:
+            out["tolfunhist"] = o["tolfunhist"]
+        if st["sigma_max_std"] < o["tolx"] and st["sigma_max_pc"] < o["tolx"]:
+            out["tolx"] = o["tolx"]
+        if st["sigma_max_std"] > self.sigma0 * o["tolfacupx"]:
+            out["tolfacupx"] = o["tolfacupx"]
+        if st["max_axis"] > o["tolconditioncov"] ** 0.5 * st["min_axis"]:
+            out["tolconditioncov"] = o["tolconditioncov"]
+        if st["sigma"] / self.sigma0 > o["tolupsigma"] * st["max_axis"]:
+            out["tolupsigma"] = o["tolupsigma"]
+        if self._flat > o["tolflatfitness"]:
+            out["tolflatfitness"] = o["tolflatfitness"]
+        nb = len(self._histbest)
+        if st["gen"] > self.n * (5 + 100 / self.lam) and nb > 100:
+            ell = int(max(o["tolstagnation"] / 5. / 2, nb / 10))        # the newest ell generations against the oldest
+            if 2 * ell < nb and (np.median(self._histmedian[-ell:]) >= np.median(self._histmedian[:ell])
+                                 and np.median(self._histbest[-ell:]) >= np.median(self._histbest[:ell])):
+                out["tolstagnation"] = o["tolstagnation"]
+        return out
+
+
+def _population_stats(fitness, order):
+    """(best, median, worst, non-finite count) of one population as csrc/ocd_cma.c computes them: NaN ranks last and
+    stays out of best / worst; the median is numpy's (NaN if any cost is NaN)."""
+    n_nan = int(np.count_nonzero(np.isnan(fitness)))
+    m = len(fitness) - n_nan
+    best = float(fitness[order[0]]) if m else np.nan
+    worst = float(fitness[order[m - 1]]) if m else np.nan
+    return best, float(np.median(fitness)), worst, int(np.count_nonzero(~np.isfinite(fitness)))
+
+
+class CMAES(_Termination):
     def __init__(self, x0, sigma0, popsize=None, seed=1):
         self.n = n = len(x0)
         self.mean = np.asarray(x0, dtype=np.float64).copy()
@@ -49,16 +157,38 @@ class CMAES:
         self._z = None
         self._best_x, self._best_f = None, np.inf
         self._told = None
+        self._z_next = None
+        self._init_termination(sigma0)
+
+    def prepare(self):
+        """Draw the next population's normal deviates now (the native twin does this while the GPU works): the
+        stream is the same, only resample() calls in between see it advanced."""
+        if self._z_next is None:
+            self._z_next = self.rng.standard_normal((self.lam, self.n))
 
     def ask(self):
         """lambda candidate vectors [lam, n]."""
-        self._z = self.rng.standard_normal((self.lam, self.n))
+        self.prepare()
+        self._z, self._z_next = self._z_next, None
         self._y = self._z @ self.sqrtC                              # C^(1/2) z, symmetric root
-        return self.mean + self.sigma * self._y
+        self._X = self.mean + self.sigma * self._y
+        return self._X
+
+    def resample(self, rows):
+        """Replace the candidates in `rows` of the population last asked for by fresh draws (pycma's rejection
+        sampling of NaN costs); returns the new rows [len(rows), n] (also written into the array ask() returned)."""
+        rows = np.atleast_1d(np.asarray(rows, dtype=np.int64))
+        for k in rows:
+            z = self.rng.standard_normal(self.n)
+            self._y[k] = self.sqrtC @ z
+            self._X[k] = self.mean + self.sigma * self._y[k]
+        return self._X[rows]
 
     def tell(self, X, fitness):
+        """Returns the number of non-finite costs (they rank last: np.argsort puts NaN after +inf)."""
         fitness = np.asarray(fitness, dtype=np.float64)
         order = np.argsort(fitness, kind="stable")
+        self._record(*_population_stats(fitness, order))
         self._update_best()                                        # (a previous generation finish_tell() did not see)
         self._told = (X, fitness, order[0])                        # best-so-far bookkeeping: finish_tell()
         self.counteval += len(fitness)
@@ -86,6 +216,7 @@ class CMAES:
         self.sqrtC = (self.B * self.Dg) @ self.B.T
         self.invsqrtC = None                                       # needed by the NEXT tell only: finish_tell()
         self.gen += 1
+        return self.last_nonfinite
 
     def finish_tell(self):
         """The part of tell() the next ask() does not need (C^-1/2 for the next path update, best-so-far): callers
@@ -112,14 +243,11 @@ class CMAES:
         self.finish_tell()
         return self._best_f
 
-    def stop(self, tolfun=1e-11, tolx=1e-11, maxiter=None, last_fitness=None):
-        if maxiter is not None and self.gen >= maxiter:
-            return True
-        if self.sigma * np.max(self.Dg) < tolx:
-            return True
-        if last_fitness is not None and self.gen > 10 and np.ptp(last_fitness) < tolfun:
-            return True
-        return False
+    def _stop_state(self):
+        d = np.sqrt(np.diag(self.C))
+        return dict(sigma=self.sigma, max_axis=float(np.max(self.Dg)), min_axis=float(np.min(self.Dg)), gen=self.gen,
+                    counteval=self.counteval, sigma_max_std=float(self.sigma * d.max()),
+                    sigma_max_pc=float(self.sigma * np.abs(self.pc).max()))
 
 
 # ---------------------------------------------------------------- native implementation (csrc/ocd_cma.c)
@@ -134,12 +262,21 @@ def load_cma_library():
         return _CMA_LIB
     here = os.path.dirname(os.path.abspath(__file__))
     path = os.path.join(os.path.dirname(os.path.dirname(here)), "csrc", "libocd_cma.so")
-    if not os.path.exists(path):
+    root = os.path.dirname(os.path.dirname(os.path.dirname(here)))
+    srcs = [os.path.join(os.path.dirname(path), "ocd_cma.c"), os.path.join(root, "include", "ocd_cma.h")]
+    stale = (not os.path.exists(path)) or any(
+        os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(path) for f in srcs)
+    if stale:                                                       # plain gcc, no GPU involved; a no-op when current
         import subprocess
         r = subprocess.run(["make", "-C", os.path.dirname(path), "libocd_cma.so"], capture_output=True, text=True)
-        if r.returncode != 0:
+        if r.returncode != 0 and not os.path.exists(path):
             raise FileNotFoundError(f"{path} is missing and could not be built:\n{r.stderr[-1500:]}")
     lib = C.CDLL(path)
+    want = _header_abi_version(srcs[1])
+    have = lib.ocd_cma_abi_version() if hasattr(lib, "ocd_cma_abi_version") else 1
+    if want is not None and have != want:
+        raise RuntimeError(f"{path} was built for ocd_cma.h ABI {have}, the header says {want}: run `make -C "
+                           f"{os.path.dirname(path)}` (a stale library would silently mismatch the ctypes signatures)")
     lib.ocd_cma_create.restype = C.c_int32
     lib.ocd_cma_create.argtypes = [C.c_int32, _D, C.c_double, C.c_int32, C.c_uint32, C.POINTER(C.c_void_p)]
     lib.ocd_cma_destroy.restype = None
@@ -152,12 +289,27 @@ def load_cma_library():
     lib.ocd_cma_prepare.argtypes = [C.c_void_p]
     lib.ocd_cma_tell.restype = C.c_int32
     lib.ocd_cma_tell.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ocd_cma_resample.restype = C.c_int32
+    lib.ocd_cma_resample.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    lib.ocd_cma_stop_state.restype = C.c_int32
+    lib.ocd_cma_stop_state.argtypes = [C.c_void_p, C.c_void_p]
+    lib.ocd_cma_abi_version.restype = C.c_int32
+    lib.ocd_cma_abi_version.argtypes = []
     lib.ocd_cma_state.restype = C.c_int32
     lib.ocd_cma_state.argtypes = [C.c_void_p, _D, _D, _D, _D, _D, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _D]
     lib.ocd_fitness_from_returns.restype = C.c_int32
     lib.ocd_fitness_from_returns.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]
     _CMA_LIB = lib
     return lib
+
+
+def _header_abi_version(header):
+    import re
+    try:
+        m = re.search(r"#define\s+OCD_CMA_ABI_VERSION\s+(\d+)", open(header).read())
+    except OSError:
+        return None
+    return int(m.group(1)) if m else None
 
 
 def fitness_from_returns_native(returns: np.ndarray, P: int, N: int, S: int, out: np.ndarray = None) -> np.ndarray:
@@ -170,7 +322,7 @@ def fitness_from_returns_native(returns: np.ndarray, P: int, N: int, S: int, out
     return cost
 
 
-class NativeCMAES:
+class NativeCMAES(_Termination):
     """The same ask / tell interface as CMAES over csrc/ocd_cma.c."""
 
     def __init__(self, x0, sigma0, popsize=None, seed=1):
@@ -188,6 +340,9 @@ class NativeCMAES:
         self._X_ptr = self._X.ctypes.data
         self._f = np.empty(self.lam, dtype=np.float64)
         self._f_ptr = self._f.ctypes.data
+        self._ss = np.empty(13, dtype=np.float64)
+        self._ss_ptr = self._ss.ctypes.data
+        self._init_termination(sigma0)
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -201,19 +356,37 @@ class NativeCMAES:
             raise RuntimeError("ocd_cma_ask failed")
         return self._X
 
+    def resample(self, rows):
+        """Replace the candidates in `rows` of the population last asked for by fresh draws (pycma's rejection
+        sampling of NaN costs); returns the new rows [len(rows), n] (also written into ask()'s array)."""
+        rows = np.atleast_1d(np.asarray(rows, dtype=np.int64))
+        for k in rows:
+            if self.lib.ocd_cma_resample(self._h, int(k), self._X_ptr) != 0:
+                raise IndexError(f"ocd_cma_resample: no slot {int(k)} in a population of {self.lam}")
+        return self._X[rows]
+
     def tell(self, X, fitness):
-        if X is not self._X:
-            self._X[...] = X
+        """The update from the population last asked for.  X must BE that population (the array ask() returned, rows
+        replaced by resample() included): the native update uses the steps it drew, not the numbers in X -- a
+        modified X is refused.  Returns the number of non-finite costs (ranked last)."""
+        if X is not self._X and not np.array_equal(X, self._X):
+            raise ValueError("tell(X, ...) must get the population ask() returned, unmodified")
         self._f[...] = fitness
-        if self.lib.ocd_cma_tell(self._h, self._X_ptr, self._f_ptr) != 0:
+        nonfinite = self.lib.ocd_cma_tell(self._h, self._X_ptr, self._f_ptr)
+        if nonfinite < 0:
             raise RuntimeError("ocd_cma_tell failed")
+        self.lib.ocd_cma_stop_state(self._h, self._ss_ptr)
+        ss = self._ss
+        self._record(ss[5], ss[6], ss[7], nonfinite)
+        return nonfinite
 
     def finish_tell(self):                                         # (the numpy twin defers work; nothing to do here)
         pass
 
     def prepare(self):
         """Draw the next population's normal deviates now (while the GPU runs this generation): same stream."""
-        self.lib.ocd_cma_prepare(self._h)
+        if self.lib.ocd_cma_prepare(self._h) != 0:
+            raise RuntimeError("ocd_cma_prepare failed")
 
     def _state(self):
         n = self.n
@@ -233,12 +406,8 @@ class NativeCMAES:
     gen = property(lambda self: self._state()["gen"])
     counteval = property(lambda self: self._state()["counteval"])
 
-    def stop(self, tolfun=1e-11, tolx=1e-11, maxiter=None, last_fitness=None):
-        st = self._state()
-        if maxiter is not None and st["gen"] >= maxiter:
-            return True
-        if st["sigma"] * st["max_axis"] < tolx:
-            return True
-        if last_fitness is not None and st["gen"] > 10 and np.ptp(last_fitness) < tolfun:
-            return True
-        return False
+    def _stop_state(self):
+        self.lib.ocd_cma_stop_state(self._h, self._ss_ptr)
+        ss = self._ss
+        return dict(sigma=ss[0], max_axis=ss[1], min_axis=ss[2], gen=int(ss[3]), counteval=int(ss[4]),
+                    sigma_max_std=ss[10], sigma_max_pc=ss[11])

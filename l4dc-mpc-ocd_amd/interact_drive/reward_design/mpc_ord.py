@@ -5,6 +5,7 @@ point ([P, D] -> [P]) that one CMA-ES generation needs and the GPU is built for.
 torch.distributed initialised (backend "nccl" = RCCL), candidates are sharded over the ranks and the
 per-episode returns are all-gathered once per call (sharding.py).
 """
+import copyreg
 import pickle
 import time
 
@@ -18,37 +19,78 @@ from ... import abi, sharding
 from ...scenarios import planner_weights_fp32, planner_weights_fp32_batch, row_dots
 
 
-class list2(list):  # mutable list that can carry a .seed attribute (mpc_ord.py:10-12)
+_REF_MODULE = "interact_drive.reward_design.mpc_ord"
+
+
+class _ModuleByName:
+    """Pickles as importlib.import_module(name): a module reference that needs nothing of this package to load."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __reduce__(self):
+        import importlib
+        return importlib.import_module, (self.name,)
+
+
+class _PickledUnderReferencePath(type):
+    """Metaclass of list2: the CLASS pickles as getattr(import_module('interact_drive.reward_design.mpc_ord'),
+    'list2') (registered with copyreg below; pickle consults the dispatch table for classes with a custom metaclass
+    before it falls back to a by-name global).  History pickles therefore name the reference's module path -- its
+    own scripts load them (bar_plot.py:105-130, generalization_plot.py:167-177) -- and dumping imports nothing and
+    registers nothing in sys.modules."""
+
+
+def _reduce_list2_class(cls):
+    return getattr, (_ModuleByName(_REF_MODULE), cls.__name__)
+
+
+copyreg.pickle(_PickledUnderReferencePath, _reduce_list2_class)
+
+
+class list2(list, metaclass=_PickledUnderReferencePath):  # mutable list that can carry a .seed attribute (mpc_ord.py:10-12)
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
 
 
-def _pickle_as_reference_list2():
-    """History pickles must load in the reference's own scripts (bar_plot.py:105-130, generalization_plot.py:
-    167-177 unpickle `interact_drive.reward_design.mpc_ord.list2`): the class is pickled under the reference's
-    module path.  pickle resolves that dotted name by importing it, parents included, so the leaf name is aliased
-    to this module and -- only where no package of that name is loaded -- the two parents are registered as EMPTY
-    stub packages (`__path__ = []`).  The stubs hold nothing but the chain down to this module: a later
-    `import interact_drive.car` raises ModuleNotFoundError instead of silently loading a second copy of the mirror
-    under another name, and the reference is never imported as a side effect.  If a real `interact_drive` is already
-    loaded, nothing is registered and list2 keeps this module's own path."""
+class _ReferencePathFinder:
+    """LOADING such a pickle in a process that has this package but not the reference: a finder at the END of
+    sys.meta_path resolves `interact_drive`, `interact_drive.reward_design` and `...mpc_ord` -- the two parents as
+    empty stub packages, the leaf as this module -- only when no other finder did, i.e. only when the real
+    `interact_drive` is not importable.  Where it is (side-by-side comparison, the reference's plot scripts) the
+    real package wins and nothing here is registered; until somebody imports one of the three names nothing is
+    registered either.  The stubs hold no other name: `import interact_drive.car` still raises
+    ModuleNotFoundError instead of loading a second copy of the mirror under another name."""
+
+    _names = ("interact_drive", "interact_drive.reward_design", _REF_MODULE)
+
+    @classmethod
+    def find_spec(cls, fullname, path=None, target=None):
+        if fullname not in cls._names:
+            return None
+        import importlib.machinery
+        return importlib.machinery.ModuleSpec(fullname, cls, is_package=fullname != _REF_MODULE)
+
+    @staticmethod
+    def create_module(spec):
+        import sys
+        import types
+        if spec.name == _REF_MODULE:
+            return sys.modules[__name__]
+        stub = types.ModuleType(spec.name, "stub package: only names the reference path of MPC_ORD history pickles")
+        stub.__path__ = []
+        stub._ocd_pickle_stub = True
+        return stub
+
+    @staticmethod
+    def exec_module(module):
+        pass
+
+
+def _install_reference_path_finder():
     import sys
-    import types
-    ref = "interact_drive.reward_design.mpc_ord"
-    here = sys.modules[__name__]
-    top, mid = "interact_drive", "interact_drive.reward_design"
-    if top in sys.modules and not getattr(sys.modules[top], "_ocd_pickle_stub", False):
-        return                                                       # the real package (or somebody else's) is loaded
-    for name in (top, mid):
-        if name not in sys.modules:
-            stub = types.ModuleType(name, "stub package: only names the reference path of MPC_ORD history pickles")
-            stub.__path__ = []
-            stub._ocd_pickle_stub = True
-            sys.modules[name] = stub
-    sys.modules[top].reward_design = sys.modules[mid]
-    sys.modules[mid].mpc_ord = here
-    sys.modules[ref] = here
-    list2.__module__ = ref
+    if not any(f is _ReferencePathFinder for f in sys.meta_path):
+        sys.meta_path.append(_ReferencePathFinder)
 
 
 class MPC_ORD:
@@ -71,6 +113,8 @@ class MPC_ORD:
         self._pending_history = None
         self._defer_history = False
         self._overlap_hooks = []
+        self.n_nonfinite = []            # per eval_population call: costs that came back NaN or +-inf
+        self.max_nan_resamples = 10      # rounds of pycma-style rejection sampling per generation
 
     # ------------------------------------------------------------------ GPU plumbing
     def _engine(self):
@@ -98,8 +142,11 @@ class MPC_ORD:
         device buffer for the returns, which the RCCL all-gather needs."""
         import torch
         key = (str(eng.device), P, N, S, D, n_local)
-        st = getattr(self, "_stage", None)
-        if st is None or st["key"] != key:
+        cache = self.__dict__.setdefault("_stages", {})            # a resampled sub-population has its own shape
+        st = cache.get(key)
+        if st is None:
+            if len(cache) >= 8:
+                cache.clear()
             st = dict(key=key,
                       w_host=torch.empty((P, D), dtype=torch.float32).pin_memory(),
                       ret_dev=torch.empty((n_local,), dtype=torch.float32, device=eng.device),
@@ -110,7 +157,7 @@ class MPC_ORD:
             st["w_ptr"] = st["w_host"].data_ptr()
             st["ret_dev_ptr"] = st["ret_dev"].data_ptr()
             st["ret_host_ptr"] = st["ret_host"].data_ptr()
-            self._stage = st
+            cache[key] = st
         return st
 
     def _flush_history(self):
@@ -218,6 +265,8 @@ class MPC_ORD:
         self.last_returns = ret
         P, N, S = ret.shape
         cost = fitness_from_returns_native(ret.reshape(-1), P, N, S)    # == sharding.fitness_from_returns, one C call
+        # a runaway trajectory (the dynamics have no speed floor) scores inf or NaN: counted, never hidden
+        self.n_nonfinite.append(P - int(np.isfinite(cost).sum()))
         self._pending_history = (hist["Wn"], cost)
         if not self._defer_history:
             self._flush_history()
@@ -241,7 +290,14 @@ class MPC_ORD:
         return float(self.eval_population(weights[None])[0])
 
     def optimize_cmaes(self, seed=1, sigma0=0.1, popsize=None, maxiter=None, maxfevals=None):
-        """mpc_ord.py:33-45, with whole generations evaluated per launch."""
+        """mpc_ord.py:33-45, with whole generations evaluated per launch.
+
+        Around the sampler this follows what pycma's fmin2 does with the reference's fitness callable: a candidate
+        whose cost is NaN is rejected and redrawn (ask_and_eval; at most `max_nan_resamples` rounds per generation,
+        each one small launch -- what is still NaN then ranks last), every evaluation lands in the history, and the
+        run ends on pycma's default termination rules (cmaes._Termination: maxiter = 100 + 150 (N+3)^2 / sqrt(popsize)
+        unless `maxiter` is given, tolfun, tolfunhist, tolx, tolstagnation, condition of C, ...).  `self.stop_reason`
+        keeps the satisfied conditions, `self.n_nonfinite` the non-finite costs per evaluation call."""
         self.history.seed = seed
         assert seed != 0
         assert not self.done
@@ -251,29 +307,50 @@ class MPC_ORD:
         self.generation_seconds = []
         self.fitness_seconds = []
         self.host_split = {}
+        self.n_resampled = 0
+        self.stop_reason = {}
         self._eng_fixed = self._engine()                           # world and car do not change inside the loop
         self._defer_history = self.save_path is None               # (a saved history must be complete at every dump)
         self._overlap_hooks = [es.prepare]                          # the next population's deviates, while the GPU works
-        while True:
-            t0 = time.perf_counter()                               # a generation: ask, fitness of the population, tell
-            X = es.ask()
-            t1 = self._tick("ask", t0)
-            f = self.eval_population(X)
-            t2 = time.perf_counter()
-            self.fitness_seconds.append(t2 - t1)
-            es.tell(X, f)
-            self._tick("tell", t2)
-            self.generation_seconds.append(time.perf_counter() - t0)
-            if es.stop(maxiter=maxiter, last_fitness=f) or (maxfevals and es.counteval >= maxfevals):
-                break
-        self._eng_fixed = None
-        self._defer_history = False
-        self._overlap_hooks = []
-        self._flush_history()
+        try:
+            while True:
+                t0 = time.perf_counter()                           # a generation: ask, fitness of the population, tell
+                X = es.ask()
+                t1 = self._tick("ask", t0)
+                f = self.eval_population(X)
+                if np.isnan(f).any():
+                    f = self._resample_nan(es, X, f)
+                t2 = time.perf_counter()
+                self.fitness_seconds.append(t2 - t1)
+                es.tell(X, f)
+                self._tick("tell", t2)
+                self.generation_seconds.append(time.perf_counter() - t0)
+                why = es.stop(maxiter=maxiter, maxfevals=maxfevals)
+                if why:
+                    self.stop_reason = why
+                    break
+        finally:                                                   # also on an exception or Ctrl-C inside a long run
+            self._eng_fixed = None
+            self._defer_history = False
+            self._overlap_hooks = []
+            self._flush_history()
         self.should_save_history = False
         self.done = True
         self.es = es
         return es.best_x
+
+    def _resample_nan(self, es, X, f):
+        """pycma's rejection sampling (ask_and_eval behind mpc_ord.py:41): redraw and re-evaluate the candidates
+        whose cost is NaN; +-inf costs are kept (pycma keeps them too) and rank where they fall."""
+        f = np.array(f, dtype=np.float64)
+        for _ in range(self.max_nan_resamples):
+            rows = np.nonzero(np.isnan(f))[0]
+            if rows.size == 0:
+                break
+            Xr = es.resample(rows)
+            self.n_resampled += int(rows.size)
+            f[rows] = self.eval_population(Xr)
+        return f
 
     def optimize_random_search(self, n_iter=1000, seed=1):
         """mpc_ord.py:47-65: same candidate stream (np.random.rand under np.random.seed), one launch."""
@@ -287,7 +364,11 @@ class MPC_ORD:
         self.eval_population(W)
         self.should_save_history = False
         self.done = True
-        return max(self.history, key=lambda a: a[1])
+        # uniform weights in [-1, 1] can reward leaving the road: such an episode scores NaN / -inf.  The
+        # reference's max() over a history holding NaN depends on where the NaN sits (every comparison with it is
+        # False); here the best FINITE entry is returned and the others are counted in self.n_nonfinite.
+        finite = [h for h in self.history if np.isfinite(h[1])]
+        return max(finite or self.history, key=lambda a: a[1])
 
     def save_history(self):
         assert self.save_path is not None
@@ -296,7 +377,7 @@ class MPC_ORD:
             pickle.dump(self.history, file)
 
 
-_pickle_as_reference_list2()
+_install_reference_path_finder()
 
 
 def finite_horizon_env(horizon=5, env_seeds=[1], debug=True, extra_inits=False):

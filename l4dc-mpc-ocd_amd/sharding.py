@@ -36,12 +36,16 @@ _GATHER_BUFS = {}
 
 
 def gather_returns(local: torch.Tensor, P: int, N: int, S: int, group: Optional[dist.ProcessGroup] = None,
-                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   out: Optional[torch.Tensor] = None, force: bool = False) -> torch.Tensor:
     """All-gather the per-episode returns of every rank into the full [P*N*S] vector (on every rank).
     The receive buffer is kept per (device, size) and reused across generations (a generation is ~1.7 ms:
     allocations are worth avoiding), so the result is valid until the next gather of the same size -- every caller
-    copies it to the host at once.  `out`: a caller-owned [world_size * max_block] buffer instead."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    copies it to the host at once.  `out`: a caller-owned [world_size * max_block] buffer instead.
+    `force`: run the collective even in a one-rank group (bench.py --force-collective and the RCCL self-test:
+    the same all_gather_into_tensor call on device memory that N ranks make)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return local
+    if dist.get_world_size(group) == 1 and not force:
         return local
     ws = dist.get_world_size(group)
     if local.is_cuda and dist.get_backend(group) == "gloo":

@@ -20,7 +20,7 @@ def test_bench_json_line():
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "cma_generation_ms", "config2",
-              "config4_share8", "config5_share8"):
+              "config4_share8", "config5_share8", "reference_h5", "reference_h6_extra", "collective"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["dtype"] == "f32" and d["data"] == "synthetic"
     assert d["vs_baseline"] is None and d["higher_is_better"] is True and d["scaling"] == "weak"
@@ -53,3 +53,20 @@ def test_bench_json_line():
         assert sb["roofline"]["kernel_ms"] <= sb["ms_per_step"] * 1.02
     sp = d["cma"]["host_split_ms"]
     assert set(sp) >= {"ask", "normalise", "launch", "kernel_gather_readback", "reduce", "tell"}
+    # the launch kernel_ms times writes where the timed step's launch writes
+    assert rf["launch"]["returns_written_to"].startswith("pinned host memory")
+    assert d["cma"]["generations_run"] == 48 and d["cma"]["generations_timed"] == 32 and d["cma"]["n_nonfinite"] == 0
+    assert d["cma"]["stop_reason"] == {"maxiter": 48.0}
+    # RCCL has executed: a one-rank group ran the real gather path on device memory (outside the timed step)
+    co = d["collective"]
+    assert "error" not in co, co
+    assert co["ranks_seen"] == 1 and co["backend"].startswith("nccl") and co["all_gather_us"] > 0 and co["in_timed_step"] is False
+    # the reference's own shapes, each with its CMA-ES generation wall-clock and a CPU figure beside it
+    r5, r6 = d["reference_h5"], d["reference_h6_extra"]
+    assert r5["episodes_per_generation"] == 27 and "H=5, n_iter=100, K=3" in r5["workload"]
+    assert r6["episodes_per_generation"] == 27 and "H=6, n_iter=200, K=6" in r6["workload"]
+    for rb in (r5, r6):
+        assert rb["cma"]["popsize"] == 9 and rb["cma_generation_ms"] > rb["roofline"]["kernel_ms"] * 0.9
+        assert rb["cpu_baseline"]["value"] > 0 and rb["cpu_baseline"]["kind"] == "port"
+    for blk in (d["config2"], s4, s5):
+        assert blk["cpu_baseline"]["value"] > 0 and blk["cpu_baseline"]["cores"] >= 1

@@ -217,6 +217,33 @@ def test_cmaes_and_random_search_drivers(hip, tmp_path):
     assert top[1] == max(h[1] for h in ord2.history)
 
 
+def test_non_finite_costs_are_counted_and_resampled(hip, oracle):
+    """A runaway episode (init speed -6: the drag term has no speed floor, simulation_utils.py:14) scores NaN for the
+    candidates that do not brake it: random search (mpc_ord.py:47-65: uniform weights in [-1, 1]) runs to completion,
+    counts them and returns the best FINITE entry; CMA-ES redraws NaN candidates the way pycma's ask_and_eval does
+    (mpc_ord.py:41), ranks what is left last and stops on the iteration cap."""
+    car, world, _ = finite_horizon_env(horizon=5, env_seeds=[1])
+    inits = [np.array([0.0, -0.9, 0.8, PI_2]), np.array([0.02, -0.9, -6.0, PI_2])]
+    ord_ = MPC_ORD(world, car, inits, 15)
+    top = ord_.optimize_random_search(n_iter=40, seed=5)
+    np.random.seed(5)
+    W = np.stack([np.random.rand(7) * 2 - 1 for _ in range(40)])
+    scn = scenarios.finite_horizon(horizon=5)
+    ret = oracle.rollout(scn.desc, np.stack(inits), scenarios.planner_weights_fp32_batch(W))["returns"]
+    cost = sharding.fitness_from_returns(ret, 40, 2, 1)
+    n_bad = int((~np.isfinite(cost)).sum())
+    assert 5 <= n_bad <= 35 and sum(ord_.n_nonfinite) == n_bad and ord_.n_nonfinite[0] == 0
+    assert len(ord_.history) == 41 and np.isfinite(top[1]) and top[1] == max(h[1] for h in ord_.history if np.isfinite(h[1]))
+    assert top[1] >= -np.nanmin(cost)
+    ord2 = MPC_ORD(world, car, inits, 15)
+    best = ord2.optimize_cmaes(seed=3, sigma0=0.3, popsize=16, maxiter=3)
+    assert ord2.stop_reason == {"maxiter": 3} and ord2.done and np.all(np.isfinite(best))
+    assert ord2.n_resampled > 0 and sum(ord2.n_nonfinite) >= ord2.n_resampled
+    assert len(ord2.history) == 1 + 3 * 16 + ord2.n_resampled          # every evaluation lands in the history
+    assert ord2.es.nonfinite_total < sum(ord2.n_nonfinite)              # most NaN slots were replaced before tell()
+    assert np.isfinite(ord2.es.best_f)
+
+
 def test_reward_fn_and_features_match_oracle(hip, oracle):
     car, world, inits = finite_horizon_env(horizon=5, env_seeds=[4])
     scn = scenarios.finite_horizon(horizon=5)

@@ -54,3 +54,17 @@ def test_rank_emulation_runs_one_block_of_config_4():
     assert "rank 3 of a 8-way" in d["config"]["sharding"]
     # value counts this GPU's episodes only
     assert abs(d["value"] - 2048 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+
+
+def test_rccl_runs_in_a_one_rank_group():
+    """--force-collective: a one-rank RCCL ("nccl") process group, and every timed step goes through
+    sharding.gather_returns on device tensors -- the code path N ranks run (bench.py init_group, sharding.py
+    all_gather_into_tensor) executed on the one GPU of this box; same costs as the plain run."""
+    plain = run(["--gpus", "1"] + COMMON)
+    forced = run(["--gpus", "1", "--force-collective", "--master-port", str(30300 + os.getpid() % 200)] + COMMON)
+    co = forced["collective"]
+    assert co["ranks_seen"] == 1 and co["backend"].startswith("nccl") and co["in_timed_step"] is True
+    assert co["all_gather_us"] > 0 and co["bytes_per_rank"] == 2048 * 4
+    assert forced["roofline"]["launch"]["returns_written_to"] == "device memory"
+    assert forced["generation_cost_checksum"] == plain["generation_cost_checksum"]
+    assert plain["collective"] is None            # --no-extras: no collective anywhere in a plain one-GPU run

@@ -208,9 +208,108 @@ def test_cma_library_exports_what_its_header_declares():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     names = re.findall(r"^\w[\w\s\*]*?\b(ocd_\w+)\s*\(", open(os.path.join(root, "include", "ocd_cma.h")).read(), re.M)
     assert set(names) >= {"ocd_cma_create", "ocd_cma_destroy", "ocd_cma_ask", "ocd_cma_tell", "ocd_cma_prepare",
-                          "ocd_cma_state", "ocd_cma_popsize", "ocd_fitness_from_returns"}
+                          "ocd_cma_state", "ocd_cma_popsize", "ocd_fitness_from_returns", "ocd_cma_resample",
+                          "ocd_cma_stop_state", "ocd_cma_abi_version"}
     for n in names:
         assert isinstance(getattr(lib, n), ctypes._CFuncPtr), n
+
+
+def test_cmaes_twins_stay_identical_through_non_finite_costs():
+    """VERDICT round 3 / ADVICE: one NaN cost used to stay wherever the native insertion sort put it (ranked best).
+    Both twins rank NaN last (np.argsort's order), count non-finite costs, and redraw a slot the same way."""
+    from l4dc_mpc_ocd_amd.interact_drive.reward_design.cmaes import NativeCMAES
+    for fit in ([3, np.nan, 1, 2, 0.5, 4], [np.nan, np.nan, 1, 2, 0.5, 4], [np.inf, 3, np.nan, -np.inf, 0.5, 4],
+                [np.nan] * 6):
+        a, b = CMAES([0.0] * 4, 0.2, popsize=6, seed=5), NativeCMAES([0.0] * 4, 0.2, popsize=6, seed=5)
+        Xa, Xb = a.ask(), b.ask()
+        na, nb = a.tell(Xa, fit), b.tell(Xb, fit)
+        assert na == nb == int(np.sum(~np.isfinite(fit))) and a.last_nonfinite == b.last_nonfinite == na
+        assert np.allclose(a.mean, b.mean, rtol=0, atol=1e-12) and abs(a.sigma - b.sigma) < 1e-12, fit
+        if not np.all(np.isnan(fit)):
+            assert a.best_f == b.best_f == np.nanmin(fit)
+    # the native ranking IS np.argsort(kind='stable') on costs with NaN / inf / ties: a population whose best
+    # candidates are unique picks the same mean
+    rng = np.random.default_rng(3)
+    f = lambda X: np.sum((X - 0.3) ** 2, axis=1)
+    a, b = CMAES([0.5] * 7, 0.2, popsize=16, seed=11), NativeCMAES([0.5] * 7, 0.2, popsize=16, seed=11)
+    total = 0
+    for g in range(40):
+        Xa, Xb = a.ask(), b.ask()
+        assert np.abs(Xa - Xb).max() < 1e-9, g
+        fa = f(Xa)
+        bad = rng.random(16) < 0.25
+        fa[bad] = rng.choice([np.nan, np.inf, -np.inf, np.nan], size=int(bad.sum()))
+        a.prepare(); b.prepare()                                     # (optimize_cmaes draws ahead while the GPU works)
+        rows = np.nonzero(np.isnan(fa))[0][:2]                       # pycma-style rejection of (some of) the NaN slots
+        if rows.size:
+            Ra, Rb = a.resample(rows), b.resample(rows)
+            assert np.abs(Ra - Rb).max() < 1e-9 and np.array_equal(Xb[rows], Rb) and np.array_equal(Xa[rows], Ra)
+            fa[rows] = f(Ra)
+        na, nb = a.tell(Xa, fa), b.tell(Xb, fa)
+        total += na
+        assert na == nb == int(np.sum(~np.isfinite(fa)))
+        assert np.allclose(a.mean, b.mean, rtol=0, atol=1e-9) and abs(a.sigma - b.sigma) < 1e-9 * a.sigma, g
+        assert a.stop() == b.stop()
+    assert total > 20 and a.nonfinite_total == b.nonfinite_total == total
+    with pytest.raises(ValueError):                                  # tell() refuses a population it did not draw
+        X = b.ask()
+        b.tell(X + 1.0, f(X))
+    with pytest.raises(IndexError):
+        b.resample([99])
+
+
+def test_cmaes_termination_follows_pycma_defaults():
+    """mpc_ord.py:41 calls fmin2 with pycma's default options: a default iteration cap, tolfunhist on a flat
+    function, tolx on a solved one, a dict of the satisfied conditions -- the same answers from both twins."""
+    from l4dc_mpc_ocd_amd.interact_drive.reward_design.cmaes import NativeCMAES
+    for cls in (CMAES, NativeCMAES):
+        es = cls([0.0] * 7, 0.1)                                     # the reference's shape: 7 weights, popsize 9
+        assert es.lam == 9 and es.opts["maxiter"] == 100 + 150 * (7 + 3) ** 2 // 9 ** 0.5 == 5100
+        assert es.opts["tolstagnation"] == int(100 + 100 * 7 ** 1.5 / 9) and es.stop() == {}
+        for g in range(30):                                          # a constant cost: tolfun at once, flat fitness next
+            X = es.ask()
+            es.tell(X, np.full(9, 2.5))
+            why = es.stop()
+            if "tolflatfitness" in why:
+                break
+        assert "tolfun" in why and g == 1, why
+        es = cls([1.0] * 7, 0.3, seed=3)
+        for g in range(600):
+            X = es.ask()
+            es.tell(X, np.sum((X - 0.25) ** 2, axis=1))
+            why = es.stop()
+            if why:
+                break
+        assert ("tolfun" in why or "tolx" in why or "tolfunhist" in why) and es.best_f < 1e-12 and g < 599, why
+        es = cls([1.0] * 7, 0.3, seed=3)
+        for g in range(50):
+            X = es.ask()
+            es.tell(X, np.sum((X - 0.25) ** 2, axis=1))
+            if es.stop(maxiter=7):
+                break
+        assert g == 6 and es.stop(maxiter=7) == {"maxiter": 7} and es.stop(maxfevals=20) == {"maxfevals": 20}
+        with pytest.raises(TypeError):
+            es.stop(tolfoo=1)
+        es = cls([0.0] * 3, 1e-3, seed=2)                            # a step size far too small: tolfacupx
+        for g in range(400):
+            X = es.ask()
+            es.tell(X, -X[:, 0])                                     # unbounded descent direction
+            why = es.stop()
+            if why:
+                break
+        assert "tolfacupx" in why, why
+
+
+def test_a_stale_cma_library_is_refused(tmp_path, monkeypatch):
+    """a libocd_cma.so built from an older header must not be bound silently."""
+    from l4dc_mpc_ocd_amd.interact_drive.reward_design import cmaes
+    lib = cmaes.load_cma_library()
+    assert lib.ocd_cma_abi_version() == cmaes._header_abi_version(
+        os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "ocd_cma.h"))
+    monkeypatch.setattr(cmaes, "_CMA_LIB", None)
+    monkeypatch.setattr(cmaes, "_header_abi_version", lambda path: 99)
+    with pytest.raises(RuntimeError, match="ABI"):
+        cmaes.load_cma_library()
 
 
 def test_cmaes_minimises_rosenbrock_and_is_deterministic():
@@ -297,18 +396,50 @@ def test_history_pickle_loads_in_the_reference(tmp_path):
     assert r.stdout.split() == ["interact_drive.reward_design.mpc_ord", "7", "-2.5", "[0.0,", "1.0,", "2.0]"]
 
 
-def test_pickle_alias_registers_no_mirror_package_under_the_reference_name():
-    """Only the chain of names pickle needs is registered; the mirror's packages are not reachable as
-    `interact_drive.*` (a second copy of the classes would break the isinstance checks in _describe.py)."""
-    import importlib
+def test_pickle_names_the_reference_path_without_touching_sys_modules(tmp_path):
+    """Dumping a history imports nothing and registers nothing (the class pickles through copyreg as
+    getattr(import_module('interact_drive.reward_design.mpc_ord'), 'list2')); loading one in a process without the
+    reference resolves the three names lazily through a finder at the END of sys.meta_path, so a real, importable
+    `interact_drive` always wins and `import interact_drive.car` is never shadowed by a stub."""
+    import subprocess
     import sys
-    import l4dc_mpc_ocd_amd.interact_drive.reward_design.mpc_ord as m
-    assert sys.modules["interact_drive.reward_design.mpc_ord"] is m
-    assert getattr(sys.modules["interact_drive"], "_ocd_pickle_stub", False)
-    with pytest.raises(ModuleNotFoundError):
-        importlib.import_module("interact_drive.car")
-    with pytest.raises(ModuleNotFoundError):
-        importlib.import_module("interact_drive.planner.naive_planner")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    real = tmp_path / "real" / "interact_drive"
+    (real / "reward_design").mkdir(parents=True)
+    (real / "__init__.py").write_text("REAL = True\n")
+    (real / "car.py").write_text("class Car: pass\n")
+    (real / "reward_design" / "__init__.py").write_text("")
+    (real / "reward_design" / "mpc_ord.py").write_text("class list2(list):\n    def __init__(self, *a, **k):\n        super().__init__(*a, **k)\n")
+    code = """
+import pickle, sys, importlib
+sys.path.insert(0, sys.argv[1])
+import l4dc_mpc_ocd_amd.interact_drive.reward_design.mpc_ord as m
+assert not any(k == 'interact_drive' or k.startswith('interact_drive.') for k in sys.modules), 'import registered stubs'
+h = m.list2(); h.seed = 3; h.append(([1.0], -1.0))
+raw = pickle.dumps(h)
+assert not any(k == 'interact_drive' or k.startswith('interact_drive.') for k in sys.modules), 'dump registered stubs'
+assert b'interact_drive.reward_design.mpc_ord' in raw and b'l4dc' not in raw
+if len(sys.argv) > 2:                       # the reference becomes importable later in the same process
+    sys.path.insert(0, sys.argv[2])
+    import interact_drive.car               # the REAL package, not a stub
+    assert interact_drive.REAL
+    g = pickle.loads(raw)
+    assert type(g).__module__ == 'interact_drive.reward_design.mpc_ord' and type(g) is not m.list2 and g.seed == 3
+else:                                       # no reference anywhere: the lazy finder resolves the path to the mirror's class
+    g = pickle.loads(raw)
+    assert type(g) is m.list2 and g.seed == 3 and g[0][1] == -1.0
+    assert sys.modules['interact_drive']._ocd_pickle_stub
+    try:
+        importlib.import_module('interact_drive.car')
+    except ModuleNotFoundError:
+        pass
+    else:
+        raise AssertionError('the stub package must not resolve other names')
+print('ok')
+"""
+    for extra in ([], [str(tmp_path / "real")]):
+        r = subprocess.run([sys.executable, "-c", code, root] + extra, capture_output=True, text=True, cwd=str(tmp_path))
+        assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr
 
 
 def test_history_pickle_format(tmp_path):
