@@ -353,7 +353,11 @@ def main():
         from l4dc_mpc_ocd_amd.interact_drive.experiments import run_mpc_ord as rmo
         m = rmo.make_mpc_ord(cfg["scenario"], horizon=cfg["horizon"], n_inits=cfg["n_inits"], seed=1,
                              **cfg.get("kwargs", {}))
-        m.optimize_cmaes(seed=1, sigma0=0.05, popsize=popsize, maxiter=gens)
+        # exactly `gens` generations: the step-size rules that would end this run earlier are switched off (the cost
+        # is invariant to the scale of the weights, so sigma drifts upwards: pycma's tolfacupx fires after ~38
+        # generations at pop 64)
+        m.optimize_cmaes(seed=1, sigma0=0.05, popsize=popsize, maxiter=gens,
+                         termination={"tolfacupx": float("inf"), "tolupsigma": float("inf")})
         gs = np.array(m.generation_seconds[-32:]) * 1e3
         fs = np.array(m.fitness_seconds[-32:]) * 1e3            # eval_population alone (no ask / tell)
         med = float(np.median(gs))

@@ -289,15 +289,18 @@ class MPC_ORD:
             print('eval', weights / np.linalg.norm(weights))
         return float(self.eval_population(weights[None])[0])
 
-    def optimize_cmaes(self, seed=1, sigma0=0.1, popsize=None, maxiter=None, maxfevals=None):
+    def optimize_cmaes(self, seed=1, sigma0=0.1, popsize=None, maxiter=None, maxfevals=None, termination=None):
         """mpc_ord.py:33-45, with whole generations evaluated per launch.
 
         Around the sampler this follows what pycma's fmin2 does with the reference's fitness callable: a candidate
         whose cost is NaN is rejected and redrawn (ask_and_eval; at most `max_nan_resamples` rounds per generation,
         each one small launch -- what is still NaN then ranks last), every evaluation lands in the history, and the
         run ends on pycma's default termination rules (cmaes._Termination: maxiter = 100 + 150 (N+3)^2 / sqrt(popsize)
-        unless `maxiter` is given, tolfun, tolfunhist, tolx, tolstagnation, condition of C, ...).  `self.stop_reason`
-        keeps the satisfied conditions, `self.n_nonfinite` the non-finite costs per evaluation call."""
+        unless `maxiter` is given, tolfun, tolfunhist, tolx, tolstagnation, condition of C, ...; `termination`: a dict
+        of option overrides, e.g. {"tolfacupx": inf} -- the cost is invariant to the scale of the weights
+        (mpc_ord.py:120 normalises them), so the step size drifts upwards and `tolfacupx` is what usually ends a long
+        run).  `self.stop_reason` keeps the satisfied conditions, `self.n_nonfinite` the non-finite costs per
+        evaluation call."""
         self.history.seed = seed
         assert seed != 0
         assert not self.done
@@ -325,7 +328,7 @@ class MPC_ORD:
                 es.tell(X, f)
                 self._tick("tell", t2)
                 self.generation_seconds.append(time.perf_counter() - t0)
-                why = es.stop(maxiter=maxiter, maxfevals=maxfevals)
+                why = es.stop(maxiter=maxiter, maxfevals=maxfevals, **(termination or {}))
                 if why:
                     self.stop_reason = why
                     break
