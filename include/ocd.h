@@ -324,6 +324,15 @@ int32_t ocd_reward_batch(const ocd_scenario *scn,
 int32_t ocd_debug_math(const float *in, float *exp_out, float *sin_out, float *cos_out,
                        int64_t n, void *hip_stream);
 
+/* The two-wide ("packed", v_pk_*_f32) division and exponential cores of the reward features beside their scalar
+ * forms, on caller-supplied operands: lets the tests prove on the device that the unpadded packed instruction
+ * sequences the planner kernels run give the bits of the scalar ones (IEEE division; the contract's exp for
+ * arguments <= 1), denormal numerators and quotients included.  All arrays hold 2 * n_pairs floats (pair i =
+ * elements 2i, 2i+1); num/den or x may be NULL to skip that half; any output may be NULL. */
+int32_t ocd_debug_packed_math(const float *num, const float *den, const float *x, float *div_scalar_out,
+                              float *div_packed_out, float *exp_scalar_out, float *exp_packed_out, int64_t n_pairs,
+                              void *hip_stream);
+
 /* Timing helper used by bench.py: runs `reps` back-to-back launches of
  * ocd_rollout_episodes on `hip_stream`, bracketed by HIP events recorded on
  * that same stream, and returns the mean milliseconds per launch in *ms_out

@@ -566,6 +566,21 @@ int32_t ocd_debug_math(const float *in, float *exp_out, float *sin_out, float *c
     return OCD_OK;
 }
 
+int32_t ocd_debug_packed_math(const float *num, const float *den, const float *x, float *div_scalar_out,
+                              float *div_packed_out, float *exp_scalar_out, float *exp_packed_out, int64_t n_pairs,
+                              void *hip_stream)
+{
+    if (n_pairs < 0 || (n_pairs > 0 && !((num && den) || x)) || ((num == nullptr) != (den == nullptr)))
+        return fail(OCD_ERR_INVALID_ARG, "bad arguments");
+    if (n_pairs == 0) return OCD_OK;
+    int32_t st = need_device();
+    if (st != OCD_OK) return st;
+    hipError_t e = ocd::launch_packed_math(num, den, x, div_scalar_out, div_packed_out, exp_scalar_out, exp_packed_out,
+                                           n_pairs, (hipStream_t)hip_stream);
+    if (e != hipSuccess) return hip_fail(e, "packed_math_kernel launch");
+    return OCD_OK;
+}
+
 int32_t ocd_time_rollout(const ocd_scenario *scn, const float *init_states, const float *cand_weights,
                          int64_t P, int64_t N, int64_t ep_begin, int64_t ep_end,
                          float *returns_out, int32_t reps, float *ms_out, void *hip_stream)

@@ -133,6 +133,8 @@ hipError_t launch_reward(int NO, int L, const KernelParams &p, float *feats, flo
 hipError_t launch_objective(int NO, int L, const KernelParams &p, const float *controls, float *reward_out,
                             float *grad_out, float *traj_out, hipStream_t st, bool *supported);
 hipError_t launch_math(const float *in, float *e, float *s, float *c, long long n, hipStream_t st);
+hipError_t launch_packed_math(const float *num, const float *den, const float *x, float *div_scalar, float *div_packed,
+                              float *exp_scalar, float *exp_packed, long long n_pairs, hipStream_t st);
 hipError_t launch_dynamics(const float *states, const float *controls, float dt, float dt_sq, float friction,
                            float *out, long long n, hipStream_t st);
 

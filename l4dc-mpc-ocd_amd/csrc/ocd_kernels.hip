@@ -934,6 +934,29 @@ __global__ void math_kernel(const float *in, float *e, float *s, float *c, long 
     if (c) c[i] = cv;
 }
 
+// The two-wide cores of the reward features beside their scalar forms, on caller-supplied operands: pair i is
+// (num[2i], num[2i+1]) / (den[2i], den[2i+1]) and exp of (x[2i], x[2i+1]).  Same inline-asm sequences as the planner
+// kernels run (div2_: unpadded packed Newton-Raphson steps; exp_le1_2: unpadded packed reduction + polynomial).
+__global__ void packed_math_kernel(const float *num, const float *den, const float *x, float *div_scalar,
+                                   float *div_packed, float *exp_scalar, float *exp_packed, long long n_pairs)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pairs) return;
+    const PkConsts pk = pk_consts();
+    if (num && den) {
+        const v2f nn{num[2 * i], num[2 * i + 1]}, dd{den[2 * i], den[2 * i + 1]};
+        const v2f q = div2_(nn, dd);
+        if (div_packed) { div_packed[2 * i] = q.x; div_packed[2 * i + 1] = q.y; }
+        if (div_scalar) { div_scalar[2 * i] = nn.x / dd.x; div_scalar[2 * i + 1] = nn.y / dd.y; }
+    }
+    if (x) {
+        const v2f xx{x[2 * i], x[2 * i + 1]};
+        const v2f e = exp_le1_2(xx, pk);
+        if (exp_packed) { exp_packed[2 * i] = e.x; exp_packed[2 * i + 1] = e.y; }
+        if (exp_scalar) { exp_scalar[2 * i] = exp_le1(xx.x); exp_scalar[2 * i + 1] = exp_le1(xx.y); }
+    }
+}
+
 } // namespace ocd
 
 // ---------------------------------------------------------------- launch table
@@ -1110,6 +1133,16 @@ hipError_t launch_math(const float *in, float *e, float *s, float *c, long long 
     const unsigned bs = 256;
     const unsigned nb = (unsigned)((n + bs - 1) / bs);
     hipLaunchKernelGGL(math_kernel, dim3(nb), dim3(bs), 0, st, in, e, s, c, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_packed_math(const float *num, const float *den, const float *x, float *div_scalar, float *div_packed,
+                              float *exp_scalar, float *exp_packed, long long n_pairs, hipStream_t st)
+{
+    const unsigned bs = 64;                      // one wavefront per workgroup, as the planner kernels run them
+    const unsigned nb = (unsigned)((n_pairs + bs - 1) / bs);
+    hipLaunchKernelGGL(packed_math_kernel, dim3(nb), dim3(bs), 0, st, num, den, x, div_scalar, div_packed, exp_scalar,
+                       exp_packed, n_pairs);
     return hipGetLastError();
 }
 

@@ -67,6 +67,19 @@ class DeviceOps:
         return e.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy()
 
 
+    def debug_packed_math(self, num, den, x):
+        """(div_scalar, div_packed, exp_scalar, exp_packed) of 2 * n_pairs operands (include/ocd.h:
+        ocd_debug_packed_math): the planner's two-wide division / exp cores beside their scalar forms."""
+        nn, dd, xx = (self._to_dev(a).reshape(-1) for a in (num, den, x))
+        if not (nn.numel() == dd.numel() == xx.numel()) or nn.numel() % 2:
+            raise ValueError("num, den and x must hold the same even number of floats")
+        outs = [torch.empty_like(nn) for _ in range(4)]
+        self._call(self.lib.ocd_debug_packed_math, _ptr(nn), _ptr(dd), _ptr(xx), *[_ptr(o) for o in outs],
+                   nn.numel() // 2, self._stream())
+        torch.cuda.synchronize(self.device)
+        return tuple(o.cpu().numpy() for o in outs)
+
+
 _default_ops: Optional[DeviceOps] = None
 
 

@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--pop", type=int, default=0, help="override the population (e.g. the share of one of 8 GPUs)")
     ap.add_argument("--light", action="store_true", help="the build with two stamps per wavefront (make stamps_light): totals and placement only")
+    ap.add_argument("--json", action="store_true", help="one JSON line with the placement summary instead of the tables (tests/test_gpu_placement.py)")
+    ap.add_argument("--warm", type=int, default=0, help="untimed launches before the stamped one")
     a = ap.parse_args()
     os.environ["OCD_HIP_LIB"] = os.path.join(ROOT, "l4dc-mpc-ocd_amd", "csrc", "libocd_hip_stamps_light.so" if a.light else "libocd_hip_stamps.so")
     import torch
@@ -48,11 +50,27 @@ def main():
     buf = torch.zeros(nw * 16, dtype=torch.int64, device="cuda:0")
     eng.lib.ocd_debug_set_stamp_buffer.argtypes = [C.c_void_p]
     eng.lib.ocd_debug_set_stamp_buffer(buf.data_ptr())
+    for _ in range(a.warm):
+        eng.rollout(inits, w32)
+    buf.zero_()
     eng.rollout(inits, w32)
     st = buf.cpu().numpy().reshape(nw, 16)
     st = st[st[:, :11].sum(1) > 0]
     tot = st[:, :11].sum(1)
     order = np.argsort(tot)
+    if a.json:
+        import json
+        hw = st[:, 14]
+        out = dict(config=a.config, episodes=int(E), wavefronts=int(len(st)), launch=eng.last_launch(),
+                   cycles_median=float(np.median(tot)), cycles_max=float(tot.max()), cycles_min=float(tot.min()))
+        if (hw >> 40).all():
+            key = [((int(v) >> 32) & 0xf, (int(v) >> 13) & 7, (int(v) >> 12) & 1, (int(v) >> 8) & 0xf, (int(v) >> 4) & 3) for v in hw]
+            from collections import Counter
+            per_simd = Counter(key)
+            out.update(simds_used=len(per_simd), max_wavefronts_on_a_simd=max(per_simd.values()),
+                       cus_used=len({k[:4] for k in key}), xccs_used=len({k[0] for k in key}))
+        print(json.dumps(out))
+        return
     picks = [("slowest", order[-1]), ("median", order[len(order) // 2]), ("fastest", order[0])]
     print(f"config {a.config} scan_mode {a.scan_mode} segs {a.segs}: {len(st)} wavefronts, "
           f"T*(n_iter+1) = {scn.desc.episode_len * (scn.desc.n_iter + 1)} passes each")
