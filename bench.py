@@ -166,7 +166,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", type=int, default=3, help="BASELINE.json config index of the headline workload (2..5)")
+    ap.add_argument("--config", default="3",
+                    help="headline workload: BASELINE.json config index 2..5, or reference_h5 / reference_h6_extra "
+                         "(the reference's own shapes; profiling runs)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: the population grows with the ranks (config's pop per GPU); strong: the config's "
                          "population is split over the ranks (BASELINE configs 4 / 5 on 8 GPUs)")
@@ -183,6 +185,7 @@ def main():
                          "step, exactly as N ranks do")
     ap.add_argument("--plumbing-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    args.config = int(args.config) if args.config.isdigit() else args.config
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
@@ -425,7 +428,14 @@ def main():
         return out
 
     # ---- headline: the chosen config over the ranks (weak: pop per GPU; strong: pop split) ----
-    pop = scenarios.BASELINE_CONFIGS[args.config]["pop"]
+    def spec_of(cfg_index):
+        if cfg_index in REFERENCE_SHAPES:
+            return REFERENCE_SHAPES[cfg_index]
+        if cfg_index not in scenarios.BASELINE_CONFIGS or cfg_index == 1:
+            raise SystemExit(f"bench.py: --config {cfg_index}: not one of 2..5, {', '.join(REFERENCE_SHAPES)}")
+        return scenarios.BASELINE_CONFIGS[cfg_index]
+
+    pop = spec_of(args.config)["pop"]
     if emulate:
         dt, kern_ms, fit, ctx = timed_generations(args.config, pop, emulate[1], emulate[0], args.steps, args.warmup,
                                                   collective=False)
@@ -451,12 +461,14 @@ def main():
             # what ONE of 8 GPUs runs of BASELINE configs 4 / 5 (strong split): the shapes the 8-GPU lines are made of
             n_sh = max(3, min(args.steps, 20))
             shares = {f"config{c}_share8": share_block(c, 0, 8, n_sh, 2) for c in (4, 5)}
-        cfg = scenarios.BASELINE_CONFIGS[args.config]
+        cfg = spec_of(args.config)
         cma_pop = cfg["pop"] * world if args.scaling == "weak" else cfg["pop"]
         cma = cma_generations(cfg, cma_pop, reduce_over_ranks=True)
         if rank == 0 and world == 1 and not emulate:
             n_rf = max(3, min(args.steps, 20))
             for name, spec in REFERENCE_SHAPES.items():
+                if name == args.config:
+                    continue
                 dt_r, k_r, fit_r, ctx_r = timed_generations(name, spec["pop"], 1, 0, n_rf, 2, collective=False)
                 b = block(name, dt_r, k_r, ctx_r, n_rf)
                 b["generation_cost_checksum"] = float(np.sum(fit_r))

@@ -1017,7 +1017,12 @@ static hipError_t launch_mpc(const KernelParams &p_in, hipStream_t st)
         //  At horizons with neither DPP mapping (H > 16 and K*H > 64) the chunked kernel is ahead of V_LDS at every size
         //  (H = 25, 128 ... 1 024 trajectories: 3.84-4.06 ms with S = 2 against 4.52-4.94).
         const bool chunk_wins = chunk && (waves_lds > simds || (!row_cap && !seg_cap));
-        if (row_cap && n * K <= simds) variant = V_ROW;
+        // V_ROW puts the K wavefronts of a trajectory into ONE workgroup, i.e. on one compute unit: with K = 6
+        // (extra_inits) two of its four SIMDs hold two wavefronts and the workgroup waits for them at every control
+        // step -- the reference's validation shapes (27 episodes, K = 6) ran 1.7 x slower than with all K
+        // initialisations in one wavefront (round 4, tools/small_shapes.py: H = 6 4.40 -> 2.60 ms, H = 5 2.12 -> 1.26)
+        const bool row_fits_cu = K <= 4 || !seg_cap;
+        if (row_cap && n * K <= simds && row_fits_cu) variant = V_ROW;
         else if (seg_cap && waves_seg <= simds) variant = V_SEG;
         else if (chunk_wins) variant = V_CHUNK;
         else if (seg_cap && waves_seg * 20 <= waves_lds * 21 && waves_seg <= 4 * simds) variant = V_SEG;

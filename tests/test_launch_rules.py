@@ -73,6 +73,20 @@ def test_launch_rule(lib, name, H, n, expect):
     assert not ll["terminal_value"]
 
 
+def test_six_control_initialisations_share_one_wavefront(lib):
+    """extra_inits (K = 6, naive_planner.py:112-116): six wavefronts of a DPP-rows workgroup would crowd the four
+    SIMDs of one compute unit (the reference's validation shapes ran 1.7 x slower that way, tools/small_shapes.py);
+    all K initialisations go into ONE wavefront while K * H <= 64."""
+    for scn in (scenarios.finite_horizon(horizon=6, extra_inits=True), scenarios.local_opt(horizon=5, extra_inits=True)):
+        assert scn.desc.n_ctrl_inits == 6
+        assert row(plan(lib, scn, 27)) == ("one_wavefront", 0, 1, 27, 1)
+        assert row(plan(lib, scn, 1024)) == ("one_wavefront", 0, 1, 1024, 1)
+    # K = 3 keeps the DPP rows (three wavefronts on three SIMDs of a compute unit)
+    assert row(plan(lib, scenarios.finite_horizon(horizon=6), 27))[0] == "dpp_rows"
+    # K * H > 64: no one-wavefront mapping exists, the rows stay
+    assert row(plan(lib, scenarios.finite_horizon(horizon=15, extra_inits=True), 27))[0] == "dpp_rows"
+
+
 def test_forced_shapes_and_fallbacks(lib):
     scn = scenarios.local_opt(horizon=10)
     assert row(plan(lib, scn, 500, scan_mode=1))[0] == "lds_windows"

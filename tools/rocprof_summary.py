@@ -46,7 +46,7 @@ def counters_json(round_name, out_dir):
                       "(separate passes, --kernel-trace only) of `bench.py --config N [--emulate-rank 0/8] --no-extras`, kernels ocd::mpc_kernel / ocd::mpc_chunk_kernel (cfgN_share8: rank 0's block of an 8-way split); "
                       "FETCH/WRITE in KiB per launch as counted (dword-granular accesses), SQ_* per launch (quad-cycles)"}
     for d in sorted(glob.glob(os.path.join(out_dir, "c*_sq"))):
-        cfg = re.search(r"c(\d+s?)_sq", d).group(1)          # "4" = the whole config, "4s" = one of 8 GPUs' share
+        cfg = re.search(r"c(\d+s?|reference_\w+?)_sq$", d).group(1)   # "4" = the whole config, "4s" = one of 8 GPUs' share
         vals = {}
         for kind in ("fetch", "write", "sq", "stats"):
             for path in glob.glob(os.path.join(out_dir, f"c{cfg}_{kind}", "**", "*.db"), recursive=True):
@@ -70,7 +70,8 @@ def counters_json(round_name, out_dir):
         if os.path.exists(log):
             m = re.search(r'"episodes_per_gpu": (\d+)', open(log).read())
             eps = int(m.group(1)) if m else None
-        rec[f"cfg{cfg[:-1]}_share8" if cfg.endswith("s") else f"cfg{cfg}"] = {
+        key = cfg if cfg.startswith("reference_") else (f"cfg{cfg[:-1]}_share8" if cfg.endswith("s") else f"cfg{cfg}")
+        rec[key] = {
             "episodes_per_launch": eps, "fetch_kib": vals.get("FETCH_SIZE"), "write_kib": vals.get("WRITE_SIZE"),
             "sq_waves": vals.get("SQ_WAVES"), "sq_wave_cycles": vals.get("SQ_WAVE_CYCLES"), "sq_busy_cycles": vals.get("SQ_BUSY_CYCLES"),
             "sq_insts_valu": vals.get("SQ_INSTS_VALU"), "sq_active_inst_valu": vals.get("SQ_ACTIVE_INST_VALU"),
