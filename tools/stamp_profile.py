@@ -62,7 +62,8 @@ def main():
         import json
         hw = st[:, 14]
         out = dict(config=a.config, episodes=int(E), wavefronts=int(len(st)), launch=eng.last_launch(),
-                   cycles_median=float(np.median(tot)), cycles_max=float(tot.max()), cycles_min=float(tot.min()))
+                   cycles_median=float(np.median(tot)), cycles_max=float(tot.max()), cycles_min=float(tot.min()),
+                   cycles_p99=float(np.percentile(tot, 99)), cycles_p01=float(np.percentile(tot, 1)))
         if (hw >> 40).all():
             key = [((int(v) >> 32) & 0xf, (int(v) >> 13) & 7, (int(v) >> 12) & 1, (int(v) >> 8) & 0xf, (int(v) >> 4) & 3) for v in hw]
             from collections import Counter
