@@ -70,7 +70,10 @@ def check(scn, z, rollout_fn, plan_fn=None):
     ret, traj, ctrl = out["returns"].astype(np.float64), out["traj"].astype(np.float64), out["ctrl"].astype(np.float64)
     assert ret.shape == (E,) and traj.shape == z["states"].shape and ctrl.shape == z["controls"].shape
     stable = z["stable"]
-    assert stable.mean() >= 0.75, f"only {stable.sum()} of {E} episodes are fp32-stable in torch itself"
+    # at the reference's horizons nearly every episode is fp32-stable; at BASELINE's scaled-up H = 10 a hundred SGD
+    # steps amplify rounding and torch's own float32 run leaves its float64 run on most episodes
+    need = 0.75 if d.horizon <= 6 else 0.25
+    assert stable.mean() >= need, f"only {stable.sum()} of {E} episodes are fp32-stable in torch itself"
     rerr = np.abs(ret - z["sample_reward"]) / np.maximum(1e-2, np.abs(z["sample_reward"]))
     terr = np.abs(traj - z["states"]).reshape(E, -1).max(axis=1)
     cerr = np.abs(ctrl - z["controls"]).reshape(E, -1).max(axis=1)
@@ -99,7 +102,7 @@ def check(scn, z, rollout_fn, plan_fn=None):
         losses_gap = z["margin"]                                    # [E, T] best-to-second gap of the float64 losses
         clear = stable[:, None] & (losses_gap > 1e-3)
         ee, tt = np.nonzero(clear)
-        assert len(ee) >= 0.5 * E * T, f"only {len(ee)} of {E * T} plans have a decided argmin"
+        assert len(ee) >= (0.5 if d.horizon <= 6 else 0.15) * E * T, f"only {len(ee)} of {E * T} plans have a decided argmin"
         ws = z["past"][ee, tt].astype(np.float32)
         wrow = np.repeat(w32, N * S, axis=0)[ee]
         got = np.asarray(plan_fn(ws, wrow)).astype(np.int32)
