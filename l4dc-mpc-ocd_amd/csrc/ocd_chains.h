@@ -20,6 +20,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "ocd_devmath.h"
+
 #define OCD_REP1(S) S
 #define OCD_REP2(S) S S
 #define OCD_REP4(S) S S S S
@@ -169,9 +171,10 @@ template <int HT>
 __device__ __forceinline__ void seg_fwd_xy(float &x, float &y, float ex, float ey, float cd, float sd,
                                            unsigned long long first_mask)
 {
-    float sx, sy = ey + sd;
-#define OCD_STMT(REP)                                                                                     \
-    asm volatile("s_mov_b64 vcc, %[m]\n"                                                                  \
+    float sx, sy;                                                    // (sy = ey + sd opens the statement: no compiler-placed
+#define OCD_STMT(REP)                                                 /*  instruction between it and the caller's asm) */ \
+    asm volatile("v_add_f32 %[sy], %[ey], %[sd]\n"                                                        \
+                 "s_mov_b64 vcc, %[m]\n"                                                                  \
                  "v_add_f32 %[sx], %[ex], %[cd]\n"                                                        \
                  "v_cndmask_b32_dpp %[y], %[sy], %[ey], vcc" OCD_WAVE_SHR                                 \
                  "v_add_f32 %[sy], %[y], %[sd]\n"                                                         \
@@ -180,11 +183,53 @@ __device__ __forceinline__ void seg_fwd_xy(float &x, float &y, float ex, float e
                      "v_cndmask_b32_dpp %[y], %[sy], %[ey], vcc" OCD_WAVE_SHR                             \
                      "v_add_f32 %[sy], %[y], %[sd]\n"                                                     \
                      "v_cndmask_b32_dpp %[x], %[sx], %[ex], vcc" OCD_WAVE_SHR)                            \
-                 : [x] "=&v"(x), [y] "=&v"(y), [sx] "=&v"(sx), [sy] "+&v"(sy)                            \
+                 : [x] "=&v"(x), [y] "=&v"(y), [sx] "=&v"(sx), [sy] "=&v"(sy)                            \
                  : [cd] "v"(cd), [sd] "v"(sd), [ex] "v"(ex), [ey] "v"(ey), [m] "s"(first_mask)           \
                  : "vcc");
     OCD_CHAIN_ROUNDS_M1(HT, OCD_STMT);
 #undef OCD_STMT
+}
+
+// V_SEG, round 4: the tail of the own step's sincos (quadrant fix-up), the previous lane's (sin, cos) with the current
+// heading's at a segment's first lane, the step's increments cd / sd AND the position recurrence in ONE statement
+// (ocd_devmath.h: OCD_SC_TAIL).  hipcc pads every register an asm statement defines with a hazard s_nop before the
+// next vector instruction reads it -- also between two adjacent statements -- so fewer, longer statements are shorter
+// streams.  Same instructions as sincos_pk_seg followed by seg_fwd_xy.
+template <int HT>
+__device__ __forceinline__ void seg_sincos_fwd_xy(float thn, const ScConsts &k, float s0, float c0, float dd,
+                                                  float ex, float ey, unsigned long long first_mask,
+                                                  float &s_out, float &c_out, float &s_pre, float &c_pre,
+                                                  float &sd_out, float &cd_out, float &x, float &y)
+{
+    float n, r, cr, sn, cn, sp, cp, sd, cd, sx, sy;
+    v2f Z, P;
+    sincos_pk_head<false>(thn, k, n, r, Z, P);    // scalar chains: this statement serves launches that fill the chip
+    int32_t q, m;
+#define OCD_STMT(REP)                                                                                     \
+    asm volatile("s_mov_b64 vcc, %[fm]\n"                                                                 \
+                 OCD_SC_TAIL                                                                              \
+                 "v_cndmask_b32_dpp %[sp], %[sn], %[s0], vcc" OCD_WAVE_SHR                                \
+                 "v_mul_f32 %[sd], %[sp], %[dd]\n"                                                        \
+                 "v_cndmask_b32_dpp %[cp], %[cn], %[c0], vcc" OCD_WAVE_SHR                                \
+                 "v_add_f32 %[sy], %[ey], %[sd]\n"                                                        \
+                 "v_mul_f32 %[cd], %[cp], %[dd]\n"                                                        \
+                 "v_add_f32 %[sx], %[ex], %[cd]\n"                                                        \
+                 "v_cndmask_b32_dpp %[y], %[sy], %[ey], vcc" OCD_WAVE_SHR                                 \
+                 "v_add_f32 %[sy], %[y], %[sd]\n"                                                         \
+                 "v_cndmask_b32_dpp %[x], %[sx], %[ex], vcc" OCD_WAVE_SHR                                 \
+                 REP("v_add_f32 %[sx], %[x], %[cd]\n"                                                     \
+                     "v_cndmask_b32_dpp %[y], %[sy], %[ey], vcc" OCD_WAVE_SHR                             \
+                     "v_add_f32 %[sy], %[y], %[sd]\n"                                                     \
+                     "v_cndmask_b32_dpp %[x], %[sx], %[ex], vcc" OCD_WAVE_SHR)                            \
+                 : [q] "=&v"(q), [m] "=&v"(m), [cr] "=&v"(cr), [sr] "+&v"(r), [sn] "=&v"(sn), [cn] "=&v"(cn),     \
+                   [sp] "=&v"(sp), [cp] "=&v"(cp), [sd] "=&v"(sd), [cd] "=&v"(cd), [x] "=&v"(x), [y] "=&v"(y),    \
+                   [sx] "=&v"(sx), [sy] "=&v"(sy)                                                         \
+                 : [n] "v"(n), [px] "v"(P.x), [py] "v"(P.y), [zx] "v"(Z.x), [zy] "v"(Z.y), [k] "s"(0x80000000u),   \
+                   [s0] "v"(s0), [c0] "v"(c0), [dd] "v"(dd), [ex] "v"(ex), [ey] "v"(ey), [fm] "s"(first_mask)     \
+                 : "vcc");
+    OCD_CHAIN_ROUNDS_M1(HT, OCD_STMT);
+#undef OCD_STMT
+    s_out = sn; c_out = cn; s_pre = sp; c_pre = cp; sd_out = sd; cd_out = cd;
 }
 
 // (Tried for V_SEG: the position recurrences without boundary selects -- a DPP operand cannot read a lane EXEC

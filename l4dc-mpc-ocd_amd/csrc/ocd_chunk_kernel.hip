@@ -120,6 +120,8 @@ mpc_chunk_kernel(const KernelParams p)
 
     const int T = p.T;
     const PkConsts pkc = pk_consts();
+    ScConsts scc;                              // coefficient pairs of the two-wide sin / cos polynomials (latency builds)
+    if constexpr (LAT) scc = sc_consts();
     // The latency build wants its SIMD to itself, and the workgroup dispatcher does not promise that: in the diagnostic
     // build (make stamps; a third of the register file per wavefront) it put two of the 1 024 single-wavefront
     // workgroups on every tenth SIMD and none on as many others, and those wavefronts took 1.5x as long
@@ -282,7 +284,11 @@ mpc_chunk_kernel(const KernelParams p)
                     v = v + acc * dt;
                     th = th + wdt[s];
                     vn[s] = v;
-                    sincos_(th, sn[s], cn[s]);
+                    // latency builds: two-wide polynomial chains + bit-select quadrant swap (-1.1 ... -1.4 % at the per-GPU
+                    // shares of configs 4 / 5); the throughput builds keep the scalar form: the coefficient pairs
+                    // cost 8 VGPRs, which the three-per-SIMD builds pay in scratch (config 5 whole +8 %, measured)
+                    if constexpr (LAT) sincos_pk(th, sn[s], cn[s], scc);
+                    else sincos_(th, sn[s], cn[s]);
                 }
                 if constexpr (SL < S) {
 #pragma unroll

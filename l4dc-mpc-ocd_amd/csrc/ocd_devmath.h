@@ -25,12 +25,23 @@ namespace ocd {
 
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
-// round to nearest-even integer for |v| < 2^22 (1.5 * 2^23 trick; the asm
-// barrier keeps the add and the subtract from being folded)
+// round to nearest-even integer for |v| < 2^22 (1.5 * 2^23 trick; the asm barrier keeps the add and the subtract
+// from being folded)
 __device__ __forceinline__ float rint_small(float v)
 {
     float t = v + 12582912.0f;
     asm volatile("" : "+v"(t));
+    return t - 12582912.0f;
+}
+
+// The same two additions without the barrier: hipcc may not reassociate (v + M) - M without fast-math flags, so the
+// barrier is redundant -- and it costs an issue slot per call, because hipcc pads every register an asm statement
+// "defines" with a hazard s_nop before the next vector instruction reads it.  Used by the latency builds' sincos
+// (round 4).  Everything else keeps rint_small: in the register-bound throughput builds of the chunked kernel the
+// barrier-free form moves live ranges and costs 12-32 more bytes of scratch per lane (config 5 whole +2.6 %, measured).
+__device__ __forceinline__ float rint_small_nb(float v)
+{
+    const float t = v + 12582912.0f;
     return t - 12582912.0f;
 }
 
@@ -191,6 +202,104 @@ __device__ __forceinline__ void sincos_(float x, float &s_out, float &c_out)
     // quadrant signs as a sign-bit xor (exact negation): no compare, so no mask hazard slots
     s_out = __uint_as_float(__float_as_uint(sv) ^ (((uint32_t)q << 30) & 0x80000000u));
     c_out = __uint_as_float(__float_as_uint(cv) ^ (((uint32_t)(q + 1) << 30) & 0x80000000u));
+}
+
+// sincos_ with the two Horner chains (sin: ((s3 z + s2) z + s1) z + s0, cos: ((c3 z + c2) z + c1) z + c0) run two-wide
+// and the quadrant swap done with bit selects instead of a compare and two v_cndmask (no mask hazard slot): the SAME
+// operations on every element, 5 instructions fewer (round 4).  The coefficient pairs live in registers.
+struct ScConsts { v2f k3, k2, k1, k0; };
+
+__device__ __forceinline__ ScConsts sc_consts()
+{
+    ScConsts k;
+    k.k3 = v2f{2.86567956e-6f, 2.44677067e-5f};
+    k.k2 = v2f{-1.98559923e-4f, -1.38877297e-3f};
+    k.k1 = v2f{8.33338592e-3f, 4.16666567e-2f};
+    k.k0 = v2f{-1.66666672e-1f, -5.00000000e-1f};
+    asm volatile("" : "+v"(k.k3), "+v"(k.k2), "+v"(k.k1), "+v"(k.k0));      // keep, do not rematerialise
+    return k;
+}
+
+#define OCD_SC_WAVE_SHR " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+// The reduction and the two Horner chains of sincos_pk: n (the quadrant count as a float), r, Z = (r^2, r^3), P = (sin
+// chain, cos chain); the callers finish with sr = fma(P.x, Z.y, r), cr = fma(P.y, Z.x, 1) and the quadrant fix-up.
+// PK = false: the two chains as scalar v_fma (round 4, measured: on a launch that fills every SIMD -- config 3 -- the
+// chip holds a lower clock under the packed chains and the launch takes 0.8 % LONGER although each wavefront needs
+// 2 % fewer cycles; launches that leave SIMDs idle -- V_ROW, small batches -- and the chunked latency builds gain the
+// full 1.1-1.4 % from the packed form: tools/ab3.sh, profiles/r04_sincos_ab.txt).
+template <bool PK = true>
+__device__ __forceinline__ void sincos_pk_head(float x, const ScConsts &k, float &n, float &r, v2f &Z, v2f &P)
+{
+    n = rint_small_nb(x * 0.636619746685028076171875f);
+    r = fma_(n, -1.57079637050628662109375f, x);
+    r = fma_(n, 4.37113882867379306e-8f, r);
+    r = fma_(n, 1.71512451000588188e-15f, r);
+    Z.x = r * r;                                // both chains multiply by Z.x (op_sel_hi picks the low half)
+    Z.y = r * Z.x;
+    if constexpr (!PK) {
+    float ps = 2.86567956e-6f, pc = 2.44677067e-5f;
+    ps = fma_(ps, Z.x, -1.98559923e-4f); pc = fma_(pc, Z.x, -1.38877297e-3f);
+    ps = fma_(ps, Z.x, 8.33338592e-3f);  pc = fma_(pc, Z.x, 4.16666567e-2f);
+    ps = fma_(ps, Z.x, -1.66666672e-1f); pc = fma_(pc, Z.x, -5.00000000e-1f);
+    P.x = ps; P.y = pc;
+    } else
+    asm("v_pk_fma_f32 %[p], %[k3], %[z], %[k2] op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %[p], %[p], %[z], %[k1] op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %[p], %[p], %[z], %[k0] op_sel_hi:[1,0,1]\n"
+        : [p] "=&v"(P) : [z] "v"(Z), [k3] "v"(k.k3), [k2] "v"(k.k2), [k1] "v"(k.k1), [k0] "v"(k.k0));
+}
+
+// quadrant: q = (int)n; odd quadrants swap sin and cos (bit select on m = -(q & 1)); the sign bits are bit 1 of q (sin)
+// and of q + 1 (cos), moved to bit 31: out = value ^ ((q << 30) & 0x80000000)   [bitop3 0x6c: B ^ (A & C)].
+// The three integer instructions come first: they cover the packed chain's result latency.
+#define OCD_SC_TAIL                                                                                                   \
+        "v_cvt_i32_f32 %[q], %[n]\n"                                                                                  \
+        "v_bfe_i32 %[m], %[q], 0, 1\n"                                                                                \
+        "v_lshlrev_b32 %[q], 30, %[q]\n"                                                                              \
+        "v_fma_f32 %[cr], %[py], %[zx], 1.0\n"                                                                        \
+        "v_fmac_f32 %[sr], %[px], %[zy]\n"                                                                            \
+        "v_bfi_b32 %[sn], %[m], %[cr], %[sr]\n"                                                                       \
+        "v_bfi_b32 %[cn], %[m], %[sr], %[cr]\n"                                                                       \
+        "v_bitop3_b32 %[sn], %[q], %[sn], %[k] bitop3:0x6c\n"                                                         \
+        "v_add_u32 %[q], 2.0, %[q]\n"                                                                                 \
+        "v_bitop3_b32 %[cn], %[q], %[cn], %[k] bitop3:0x6c\n"
+
+__device__ __forceinline__ void sincos_pk(float x, float &s_out, float &c_out, const ScConsts &k)
+{
+    float n, r, cr, sn, cn;
+    v2f Z, P;
+    sincos_pk_head(x, k, n, r, Z, P);
+    int32_t q, m;
+    asm(OCD_SC_TAIL
+        : [q] "=&v"(q), [m] "=&v"(m), [cr] "=&v"(cr), [sr] "+&v"(r), [sn] "=&v"(sn), [cn] "=&v"(cn)
+        : [n] "v"(n), [px] "v"(P.x), [py] "v"(P.y), [zx] "v"(Z.x), [zy] "v"(Z.y), [k] "s"(0x80000000u));
+    s_out = sn;
+    c_out = cn;
+}
+
+// V_SEG: the same, then the previous lane's (sin, cos) -- the current heading's at a segment's first lane -- and the
+// step's increments cd = cos_pre * dd, sd = sin_pre * dd in the SAME statement (select fused into the DPP move; each
+// DPP read comes >= 2 instructions after its source's write).
+__device__ __forceinline__ void sincos_pk_seg(float x, const ScConsts &k, float s0, float c0, float dd,
+                                              unsigned long long first_mask, float &s_out, float &c_out,
+                                              float &s_pre, float &c_pre, float &sd, float &cd)
+{
+    float n, r, cr, sn, cn, sp, cp, sdd, cdd;
+    v2f Z, P;
+    sincos_pk_head(x, k, n, r, Z, P);
+    int32_t q, m;
+    asm volatile("s_mov_b64 vcc, %[fm]\n"
+        OCD_SC_TAIL
+        "v_cndmask_b32_dpp %[sp], %[sn], %[s0], vcc" OCD_SC_WAVE_SHR
+        "v_mul_f32 %[sdd], %[sp], %[dd]\n"
+        "v_cndmask_b32_dpp %[cp], %[cn], %[c0], vcc" OCD_SC_WAVE_SHR
+        "v_mul_f32 %[cdd], %[cp], %[dd]\n"
+        : [q] "=&v"(q), [m] "=&v"(m), [cr] "=&v"(cr), [sr] "+&v"(r), [sn] "=&v"(sn), [cn] "=&v"(cn),
+          [sp] "=&v"(sp), [cp] "=&v"(cp), [sdd] "=&v"(sdd), [cdd] "=&v"(cdd)
+        : [n] "v"(n), [px] "v"(P.x), [py] "v"(P.y), [zx] "v"(Z.x), [zy] "v"(Z.y), [k] "s"(0x80000000u),
+          [s0] "v"(s0), [c0] "v"(c0), [dd] "v"(dd), [fm] "s"(first_mask)
+        : "vcc");
+    s_out = sn; c_out = cn; s_pre = sp; c_pre = cp; sd = sdd; cd = cdd;
 }
 
 } // namespace ocd

@@ -225,6 +225,8 @@ mpc_kernel(const KernelParams p)
 
     const int T = p.T;
     const PkConsts pkc = pk_consts();         // constants of the packed exp (ocd_devmath.h), pinned in registers
+    ScConsts scc;                             // coefficient pairs of the two-wide sin / cos polynomials: V_ROW latency
+    if constexpr (LAT && V == V_ROW) scc = sc_consts();   //   builds only (V_SEG runs the scalar chains, see ocd_devmath.h)
     OCD_STAMP_DECL
     float G_ret = 0.0f;
     const BumpGeom bg0 = {0.0f, 1.0f, 0.0f, 1.0f};
@@ -392,21 +394,34 @@ mpc_kernel(const KernelParams p)
             const float vn = v + acc * dt;
             const float thn = th + wdt;
             float sn, cn;
-            sincos_(thn, sn, cn);
-            float s_pre, c_pre;
-            if (V == V_ROW) {
-                s_pre = row_below(s0, sn);                 // lane 0 of the row keeps sin/cos of the current heading
-                c_pre = row_below(c0, cn);
-            } else {
-                s_pre = wave_below(sn);
-                c_pre = wave_below(cn);
-                s_pre = first ? s0 : s_pre;
-                c_pre = first ? c0 : c_pre;
-            }
-            const float cd = c_pre * dd;
-            const float sd = s_pre * dd;
-            OCD_STAMP(2);                                  // own step, sincos
+            float s_pre, c_pre, cd, sd;
+#ifdef OCD_NO_SINCOS_PK
+            constexpr bool sincos_fused = false;
             float x = ex, y = ey;
+            sincos_(thn, sn, cn);
+#else
+            // V_SEG: quadrant fix-up, boundary shift, the step's increments AND the position recurrence in one
+            // hand-scheduled statement (ocd_chains.h: seg_sincos_fwd_xy)
+            constexpr bool sincos_fused = (V == V_SEG) && asm_chains;
+            float x = ex, y = ey;
+            if constexpr (sincos_fused) seg_sincos_fwd_xy<HT>(thn, scc, s0, c0, dd, ex, ey, first_mask, sn, cn, s_pre, c_pre, sd, cd, x, y);
+            else if constexpr (LAT) sincos_pk(thn, sn, cn, scc);   // V_ROW latency build: two-wide chains, bit-select swap
+            else sincos_(thn, sn, cn);
+#endif
+            if constexpr (!sincos_fused) {
+                if (V == V_ROW) {
+                    s_pre = row_below(s0, sn);             // lane 0 of the row keeps sin/cos of the current heading
+                    c_pre = row_below(c0, cn);
+                } else {
+                    s_pre = wave_below(sn);
+                    c_pre = wave_below(cn);
+                    s_pre = first ? s0 : s_pre;
+                    c_pre = first ? c0 : c_pre;
+                }
+                cd = c_pre * dd;
+                sd = s_pre * dd;
+            }
+            OCD_STAMP(2);                                  // own step, sincos
             Q4 q;
             // LAT build of V_ROW at H = 10: the target-speed adjoint goes into the hazard slots of the position
             // recurrence (ocd_chains.h)
@@ -415,6 +430,8 @@ mpc_kernel(const KernelParams p)
                 const float tgt = d.target_speed;
                 row_fwd_xy_phi0_h10(x, y, row_below(0.0f, cd), row_below(0.0f, sd), vn, sn, cn, tgt, 4.0f * (tgt * tgt),
                                     w[0], q.qv, q.qth);
+            } else if constexpr (sincos_fused) {
+                // (the position recurrence ran inside seg_sincos_fwd_xy)
             } else if constexpr (asm_chains) {
                 if (V == V_ROW) row_fwd_xy<HT>(x, y, row_below(0.0f, cd), row_below(0.0f, sd));
                 else seg_fwd_xy<HT>(x, y, ex, ey, cd, sd, first_mask);
