@@ -40,3 +40,22 @@ def test_host_mirror_fitness_matches_the_float64_cost(oracle):
         full = z["stable"].reshape(P, -1).all(axis=1)
         assert full.any()
         np.testing.assert_allclose(cost[full], z["cost"][full], rtol=1e-4)
+
+
+@pytest.mark.parametrize("case", [c for c in tec.cases() if not c.endswith("h10")])
+def test_float64_build_of_the_oracle_follows_the_float64_episodes(case):
+    """The oracle compiled in double (`make -C oracle fp64`: every float a double, constants keep their fp32 values)
+    against the float64 torch episodes: with rounding out of the way on both sides the two restatements agree to 1e-6
+    on EVERY episode of the reference's horizons (measured 3e-7; the residue is fp32(0.1) vs 0.1-style constants) --
+    the fp32-unstable ones included, i.e. the 1e-4 of the float32 comparison is rounding, not a difference of algorithm."""
+    import oracle_lib
+    o64 = oracle_lib.load("fp64")
+    scn, z = tec.load(case)
+    w = z["planner_w32"].astype(np.float64)
+    inits = z["init_states"].astype(np.float32).astype(np.float64)         # tf.constant(init, dtype=tf.float32)
+    out = o64.rollout(scn.desc, inits, w, want_traj=True)
+    E = out["returns"].shape[0]
+    rerr = np.abs(out["returns"] - z["sample_reward"]) / np.maximum(1e-2, np.abs(z["sample_reward"]))
+    terr = np.abs(out["traj"] - z["states"]).reshape(E, -1).max(axis=1)
+    cerr = np.abs(out["ctrl"] - z["controls"]).reshape(E, -1).max(axis=1)
+    assert rerr.max() <= 1e-6 and terr.max() <= 1e-6 and cerr.max() <= 2e-6, (rerr.max(), terr.max(), cerr.max())
