@@ -287,13 +287,21 @@ def main():
         out_ptr = ret_dev.data_ptr() if sharded else host.data_ptr()   # one process: the kernel writes its returns
         n_out = e1 - e0                                                #   straight into the pinned host buffer
 
+        # the host side of a step as the product runs it (MPC_ORD._returns / eval_population): one C-ABI call on the
+        # current stream, one event wait, the native float64 reduction (csrc/ocd_cma.c, bit for bit
+        # sharding.fitness_from_returns)
+        from l4dc_mpc_ocd_amd import abi
+        from l4dc_mpc_ocd_amd.interact_drive.reward_design.cmaes import fitness_from_returns_native
+        launch, handle = eng.lib.ocd_rollout_episodes, eng._h
+        init_ptr, w_ptr, stream_ptr = init_dev.data_ptr(), w_dev.data_ptr(), eng._stream()
+        cost_buf = np.empty(hi - lo if not sharded else P, dtype=np.float64)
+
         def generation():
-            eng._call(eng.lib.ocd_rollout_episodes, eng._h, init_dev.data_ptr(), w_dev.data_ptr(), P, N, e0, e1,
-                      out_ptr, None, None, eng._stream())
+            abi.check(eng.lib, launch(handle, init_ptr, w_ptr, P, N, e0, e1, out_ptr, None, None, stream_ptr))
             if not sharded:
                 done.record()
                 done.synchronize()
-                return sharding.fitness_from_returns(host_np[:n_out], hi - lo, N, S)
+                return fitness_from_returns_native(host_np[:n_out], hi - lo, N, S, out=cost_buf)
             src = sharding.gather_returns(ret_dev, P, N, S, force=args.force_collective)
             if src.is_cuda:
                 host.copy_(src, non_blocking=True)
