@@ -218,7 +218,9 @@ def main():
         kw = {}
         if "MASTER_ADDR" not in os.environ or "WORLD_SIZE" not in os.environ:
             port = args.master_port or (31000 + os.getpid() % 2000)
-            kw = dict(init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+            import datetime
+            kw = dict(init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                      timeout=datetime.timedelta(seconds=120))       # a stuck rendezvous must raise, not hang the line
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(device), **kw)
         else:
