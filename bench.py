@@ -294,12 +294,12 @@ def main():
         # sharding.fitness_from_returns)
         from l4dc_mpc_ocd_amd import abi
         from l4dc_mpc_ocd_amd.interact_drive.reward_design.cmaes import fitness_from_returns_native
-        launch, handle = eng.lib.ocd_rollout_episodes, eng._h
+        rollout_fn, handle = eng.lib.ocd_rollout_episodes, eng._h
         init_ptr, w_ptr, stream_ptr = init_dev.data_ptr(), w_dev.data_ptr(), eng._stream()
         cost_buf = np.empty(hi - lo if not sharded else P, dtype=np.float64)
 
         def generation():
-            abi.check(eng.lib, launch(handle, init_ptr, w_ptr, P, N, e0, e1, out_ptr, None, None, stream_ptr))
+            abi.check(eng.lib, rollout_fn(handle, init_ptr, w_ptr, P, N, e0, e1, out_ptr, None, None, stream_ptr))
             if not sharded:
                 done.record()
                 done.synchronize()
