@@ -326,9 +326,10 @@ class MPC_ORD:
                 t2 = time.perf_counter()
                 self.fitness_seconds.append(t2 - t1)
                 es.tell(X, f)
-                self._tick("tell", t2)
-                self.generation_seconds.append(time.perf_counter() - t0)
+                t3 = self._tick("tell", t2)
                 why = es.stop(maxiter=maxiter, maxfevals=maxfevals, **(termination or {}))
+                self._tick("stop", t3)
+                self.generation_seconds.append(time.perf_counter() - t0)     # ask ... termination test
                 if why:
                     self.stop_reason = why
                     break
