@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 #define OCD_CMA_MAX_DIM 64
-#define OCD_CMA_ABI_VERSION 2      /* 2: ocd_cma_tell returns the non-finite count; resample, stop_state, abi_version */
+#define OCD_CMA_ABI_VERSION 3      /* 2: ocd_cma_tell returns the non-finite count; resample, stop_state, abi_version; 3: normalise_weights */
 
 typedef struct ocd_cma ocd_cma;
 
@@ -60,6 +60,12 @@ int32_t ocd_cma_stop_state(const ocd_cma *es, double out[13]);
 /* returns [P, N, S] fp32 sample rewards -> cost_out [P]: samples summed sequentially in fp32 (TensorFlow scalars,
  * mpc_ord.py:102), inits sequentially in float64 (mpc_ord.py:126,137), / S, negated (mpc_ord.py:139,151). */
 int32_t ocd_fitness_from_returns(const float *returns, int64_t P, int64_t N, int64_t S, double *cost_out);
+
+/* W [P, D] float64 candidate weights -> out [P, D] fp32 as the planning car gets them: three float64 normalisations
+ * (mpc_ord.py:120,71; linear_reward_car.py:45-47) and the fp32 cast.  `variant` names the summation order of the
+ * dot product behind np.linalg.norm on this machine (0: mul + add left to right, 1: fma left to right); the binding
+ * (scenarios.planner_weights_fp32_batch) self-checks against numpy and falls back to numpy if neither matches. */
+int32_t ocd_normalise_weights(const double *W, int64_t P, int64_t D, int32_t variant, float *out);
 
 #ifdef __cplusplus
 }

@@ -410,3 +410,28 @@ int32_t ocd_fitness_from_returns(const float *returns, int64_t P, int64_t N, int
     }
     return 0;
 }
+
+/* The three float64 normalisations a candidate goes through on its way to the planning car (mpc_ord.py:120, :71,
+ * linear_reward_car.py:45-47: weights / np.linalg.norm(weights), then the fp32 assign), for P rows of D weights.
+ * np.linalg.norm of a 1-D float64 vector is sqrt(dot(x, x)) and the dot is the BLAS numpy links: its summation order
+ * is not ours to define, so the caller picks the variant that reproduces it on THIS machine (self-check in
+ * scenarios.py) -- 0: dot = dot + x*x left to right; 1: dot = fma(x, x, dot) left to right (OpenBLAS' scalar tail
+ * loop, compiled with contraction: what numpy 2.2 does for D < 16 here) -- or keeps the numpy path. */
+int32_t ocd_normalise_weights(const double *W, int64_t P, int64_t D, int32_t variant, float *out)
+{
+    if (!W || !out || P < 0 || D < 1 || D > OCD_CMA_MAX_DIM || variant < 0 || variant > 1) return -1;
+    double row[OCD_CMA_MAX_DIM];
+    for (int64_t p = 0; p < P; ++p) {
+        for (int64_t i = 0; i < D; ++i) row[i] = W[p * D + i];
+        for (int pass = 0; pass < 3; ++pass) {
+            double dot = 0.0;
+            if (variant == 1) for (int64_t i = 0; i < D; ++i) dot = __builtin_fma(row[i], row[i], dot);
+            else for (int64_t i = 0; i < D; ++i) dot = dot + row[i] * row[i];
+            const double nrm = sqrt(dot);
+            for (int64_t i = 0; i < D; ++i) row[i] = row[i] / nrm;
+        }
+        for (int64_t i = 0; i < D; ++i) out[p * D + i] = (float)row[i];
+    }
+    return 0;
+}
+

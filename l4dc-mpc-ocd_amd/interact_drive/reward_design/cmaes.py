@@ -295,6 +295,8 @@ def load_cma_library():
     lib.ocd_cma_stop_state.argtypes = [C.c_void_p, C.c_void_p]
     lib.ocd_cma_abi_version.restype = C.c_int32
     lib.ocd_cma_abi_version.argtypes = []
+    lib.ocd_normalise_weights.restype = C.c_int32
+    lib.ocd_normalise_weights.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]
     lib.ocd_cma_state.restype = C.c_int32
     lib.ocd_cma_state.argtypes = [C.c_void_p, _D, _D, _D, _D, _D, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _D]
     lib.ocd_fitness_from_returns.restype = C.c_int32

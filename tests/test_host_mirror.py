@@ -209,7 +209,7 @@ def test_cma_library_exports_what_its_header_declares():
     names = re.findall(r"^\w[\w\s\*]*?\b(ocd_\w+)\s*\(", open(os.path.join(root, "include", "ocd_cma.h")).read(), re.M)
     assert set(names) >= {"ocd_cma_create", "ocd_cma_destroy", "ocd_cma_ask", "ocd_cma_tell", "ocd_cma_prepare",
                           "ocd_cma_state", "ocd_cma_popsize", "ocd_fitness_from_returns", "ocd_cma_resample",
-                          "ocd_cma_stop_state", "ocd_cma_abi_version"}
+                          "ocd_cma_stop_state", "ocd_cma_abi_version", "ocd_normalise_weights"}
     for n in names:
         assert isinstance(getattr(lib, n), ctypes._CFuncPtr), n
 
@@ -452,6 +452,32 @@ def test_history_pickle_format(tmp_path):
     with open(p, "rb") as f:
         g = pickle.load(f)
     assert g[0][1] == -1.5 and list(g[0][0]) == [1, 1, 1]
+
+
+def test_native_weight_normalisation_is_the_numpy_chain():
+    """csrc/ocd_cma.c:ocd_normalise_weights (three float64 normalisations + fp32 cast in one call, written straight
+    into the pinned rows the kernel reads) must be planner_weights_fp32 bit for bit; which summation order reproduces
+    numpy's BLAS dot is found by a self-check, and the numpy forms remain the fallback."""
+    from l4dc_mpc_ocd_amd import scenarios as sc
+    rng = np.random.default_rng(11)
+    for D in (2, 6, 7, 11):
+        W = rng.standard_normal((64, D)) * np.exp(rng.uniform(-3, 3, (64, 1)))
+        ref = np.stack([sc.planner_weights_fp32(r) for r in W])
+        got = sc.planner_weights_fp32_batch(W)
+        assert got.dtype == np.float32 and np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+        buf = np.zeros((64, D), dtype=np.float32)
+        assert sc.planner_weights_fp32_batch(W, out=buf) is buf and np.array_equal(buf, ref)
+        assert np.array_equal(W, W.copy())                                   # (the input is only read)
+    assert sc._NATIVE_NORMALISE.get(7) in (0, 1, None)
+    # the numpy fallback gives the same bits
+    keep = dict(sc._NATIVE_NORMALISE)
+    try:
+        for D in list(sc._NATIVE_NORMALISE):
+            sc._NATIVE_NORMALISE[D] = None
+        W = rng.standard_normal((16, 7))
+        assert np.array_equal(sc.planner_weights_fp32_batch(W), np.stack([sc.planner_weights_fp32(r) for r in W]))
+    finally:
+        sc._NATIVE_NORMALISE.update(keep)
 
 
 def test_row_dots_is_the_per_row_blas_dot():
