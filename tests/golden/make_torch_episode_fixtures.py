@@ -13,7 +13,7 @@ Cases (reference horizons: a float64 run is a meaningful target there, DESIGN.md
   finite_horizon_h5, local_opt_h5, replanning_h5, merging_h5      4 candidates x 8 inits (x 2 samples, replanning)
   finite_horizon_h6                                               H = 6 -> n_iter = 200 (mpc_ord.py:192), 2 x 4
   local_opt_h5_extra                                              extra_inits: 6 control initialisations, 2 x 4
-  finite_horizon_h10, local_opt_h10                               BASELINE configs 2 / 3's horizon, 4 x 8
+  finite_horizon_h10, local_opt_h10, replanning_h10, merging_h10  H = 10 (BASELINE configs 2 / 3's horizon), 4 x 8
 Candidates: the designer's weights (the "Iteration 0" evaluation, mpc_ord.py:39), the scenario's tuned weights
 (run_mpc_ord.py:25-42) where the reference has them, and designer + 0.05 * N(0, I) draws (run_mpc_ord.py:59).
 Inits: get_init_state(env_seed) of the scenario factories with env_seeds (seed * 1e6 + i) % 2**32
@@ -77,12 +77,15 @@ CASES = {
     # 6.1): only part of the episodes is fp32-stable even in torch -- those are held to the same 1e-4
     "finite_horizon_h10": (lambda: te.finite_horizon(10), 4, 8),
     "local_opt_h10": (lambda: te.local_opt(10), 4, 8),
+    "replanning_h10": (lambda: te.replanning(10), 4, 8),
+    "merging_h10": (lambda: te.merging(10), 4, 8),
 }
 
 
 # seeds of the designer + 0.05 N(0, I) candidate draws (explicit: adding a case must not move the others')
 CANDIDATE_SEEDS = {"finite_horizon_h5": 100, "finite_horizon_h6": 101, "local_opt_h5": 102, "local_opt_h5_extra": 103,
-                   "merging_h5": 104, "replanning_h5": 105, "finite_horizon_h10": 100, "local_opt_h10": 104}
+                   "merging_h5": 104, "replanning_h5": 105, "finite_horizon_h10": 100, "local_opt_h10": 104,
+                   "replanning_h10": 106, "merging_h10": 107}
 
 
 def make(case):

@@ -22,9 +22,9 @@ def test_oracle_matches_torch_episodes(oracle, case):
     print(case, tec.check(scn, z, rollout_fn, plan_fn))
 
 
-def test_all_eight_episode_fixtures_are_present():
+def test_all_ten_episode_fixtures_are_present():
     assert tec.cases() == ["finite_horizon_h10", "finite_horizon_h5", "finite_horizon_h6", "local_opt_h10", "local_opt_h5",
-                           "local_opt_h5_extra", "merging_h5", "replanning_h5"]
+                           "local_opt_h5_extra", "merging_h10", "merging_h5", "replanning_h10", "replanning_h5"]
 
 
 def test_host_mirror_fitness_matches_the_float64_cost(oracle):
