@@ -333,6 +333,11 @@ int32_t ocd_debug_packed_math(const float *num, const float *den, const float *x
                               float *div_packed_out, float *exp_scalar_out, float *exp_packed_out, int64_t n_pairs,
                               void *hip_stream);
 
+/* Block until everything queued on `hip_stream` (NULL = the default stream) has finished: hipStreamSynchronize behind
+ * the C ABI, for host code that holds no HIP headers -- the native CMA-ES generation loop of include/ocd_cma.h waits for
+ * its episode launch through this (mpc_ord.py:41: pycma's serial loop around the fitness callable). */
+int32_t ocd_stream_synchronize(void *hip_stream);
+
 /* Timing helper used by bench.py: runs `reps` back-to-back launches of
  * ocd_rollout_episodes on `hip_stream`, bracketed by HIP events recorded on
  * that same stream, and returns the mean milliseconds per launch in *ms_out

@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 #define OCD_CMA_MAX_DIM 64
-#define OCD_CMA_ABI_VERSION 3      /* 2: ocd_cma_tell returns the non-finite count; resample, stop_state, abi_version; 3: normalise_weights */
+#define OCD_CMA_ABI_VERSION 4      /* 2: tell returns the non-finite count; resample, stop_state, abi_version; 3: normalise_weights; 4: stop, run */
 
 typedef struct ocd_cma ocd_cma;
 
@@ -60,6 +60,50 @@ int32_t ocd_cma_stop_state(const ocd_cma *es, double out[13]);
 /* returns [P, N, S] fp32 sample rewards -> cost_out [P]: samples summed sequentially in fp32 (TensorFlow scalars,
  * mpc_ord.py:102), inits sequentially in float64 (mpc_ord.py:126,137), / S, negated (mpc_ord.py:139,151). */
 int32_t ocd_fitness_from_returns(const float *returns, int64_t P, int64_t N, int64_t S, double *cost_out);
+
+/* pycma's termination rules on the state ocd_cma_tell keeps (the best costs of the last 10 + 30 n / lambda generations,
+ * every generation's best / median cost, ...): cma.evolution_strategy.fmin2's default options around mpc_ord.py:41,
+ * restated (pycma is absent: parity unpinned; reward_design/cmaes.py:_Termination is the same logic in Python, used
+ * by the numpy twin -- the tests compare the two).  opts and flags in the order
+ *   maxiter, maxfevals, tolfun, tolfunhist, tolx, tolfacupx, tolconditioncov, tolupsigma, tolstagnation, tolflatfitness;
+ * flags[i] = 1 where condition i holds; returns how many hold (0 = go on), -1 on bad arguments. */
+int32_t ocd_cma_stop(ocd_cma *es, const double opts[10], int32_t flags[10]);
+
+/* The episode launch and the stream wait the native generation loop calls -- function pointers, so that this library
+ * stays free of HIP: ocd_rollout_episodes and ocd_stream_synchronize of include/ocd.h. */
+typedef int32_t (*ocd_cma_rollout_fn)(const void *scn, const float *init_states, const float *cand_weights, int64_t P,
+                                      int64_t N, int64_t ep_begin, int64_t ep_end, float *returns_out, float *traj_out,
+                                      float *ctrl_out, void *hip_stream);
+typedef int32_t (*ocd_cma_sync_fn)(void *hip_stream);
+
+typedef struct ocd_cma_run_args {
+    const void *scn;              /* ocd_scenario handle */
+    const float *init_dev;        /* [N, 4] device */
+    int64_t N, S;                 /* inits, samples per init */
+    float *w_pinned;              /* [lambda, n] fp32, pinned host memory the device addresses (HIP maps it): the kernel reads it */
+    float *ret_pinned;            /* [lambda * N * S] fp32, pinned host memory the kernel writes its returns into */
+    void *stream;
+    ocd_cma_rollout_fn rollout;
+    ocd_cma_sync_fn sync;
+    int32_t normalise_variant;    /* ocd_normalise_weights: the dot order that reproduces numpy here */
+    int32_t reserved;
+    int64_t max_generations;      /* at most this many generations in this call */
+    double stop_opts[10];         /* ocd_cma_stop */
+    double *X;                    /* [lambda, n] the population (also the one a pending-NaN generation is left in) */
+    double *cost;                 /* [lambda] its costs */
+    double *hist_w;               /* [max_generations, lambda, n] rows normalised once (history entries), or NULL */
+    double *hist_cost;            /* [max_generations, lambda], or NULL */
+    double *seconds;              /* [max_generations, 8]: whole generation, ask, normalise, launch, overlapped host work, wait, reduce, tell + stop; or NULL */
+    int32_t *nonfinite;           /* [max_generations] non-finite costs told, or NULL */
+} ocd_cma_run_args;
+
+/* Generations of MPC_ORD.optimize_cmaes (mpc_ord.py:33-45 around cma's fmin2) without returning to the interpreter:
+ * ask, normalise into w_pinned, launch, (next deviates + history rows while the GPU works), wait, reduce, tell, stop.
+ * Returns when a termination condition holds (stop_flags), after max_generations, or -- *pending_nan = 1 -- with a
+ * generation evaluated but NOT told because a cost is NaN: the caller redraws those candidates as pycma does
+ * (ocd_cma_resample), tells, and calls again.  *generations_done = generations told in this call. */
+int32_t ocd_cma_run(ocd_cma *es, const ocd_cma_run_args *a, int64_t *generations_done, int32_t stop_flags[10],
+                    int32_t *pending_nan);
 
 /* W [P, D] float64 candidate weights -> out [P, D] fp32 as the planning car gets them: three float64 normalisations
  * (mpc_ord.py:120,71; linear_reward_car.py:45-47) and the fp32 cast.  `variant` names the summation order of the

@@ -107,6 +107,7 @@ HIP_SYMBOLS = [
      [_VP, _VP, _VP, C.c_int32, _VP, _VP, _VP, _VP, _VP, C.c_int64, _VP]),
     ("ocd_dynamics_batch", C.c_int32, [_VP, _VP, C.c_float, C.c_float, C.c_float, _VP, C.c_int64, _VP]),
     ("ocd_reward_batch", C.c_int32, [_VP, _VP, _VP, _VP, _VP, C.c_int64, _VP]),
+    ("ocd_stream_synchronize", C.c_int32, [_VP]),
     ("ocd_debug_math", C.c_int32, [_VP, _VP, _VP, _VP, C.c_int64, _VP]),
     ("ocd_debug_packed_math", C.c_int32, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, _VP]),
     ("ocd_time_rollout", C.c_int32,

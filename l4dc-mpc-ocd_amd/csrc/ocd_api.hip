@@ -566,6 +566,15 @@ int32_t ocd_debug_math(const float *in, float *exp_out, float *sin_out, float *c
     return OCD_OK;
 }
 
+int32_t ocd_stream_synchronize(void *hip_stream)
+{
+    int32_t st = need_device();
+    if (st != OCD_OK) return st;
+    hipError_t e = hipStreamSynchronize((hipStream_t)hip_stream);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
+    return OCD_OK;
+}
+
 int32_t ocd_debug_packed_math(const float *num, const float *den, const float *x, float *div_scalar_out,
                               float *div_packed_out, float *exp_scalar_out, float *exp_packed_out, int64_t n_pairs,
                               void *hip_stream)

@@ -15,11 +15,13 @@
  * optimisation traces are "parity unpinned" (SURVEY.md 8c); the fitness values are bit-exact.
  *
  * Plain C11, no HIP: libocd_cma.so.  Declared in include/ocd_cma.h. */
+#define _POSIX_C_SOURCE 199309L   /* clock_gettime under -std=c11 */
 #include "../../include/ocd_cma.h"
 
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #define MT_N 624
 #define MT_M 397
@@ -32,6 +34,12 @@ struct ocd_cma {
     double fit_best, fit_median, fit_worst;   /* of the population last told (non-finite costs excluded from best / worst) */
     int64_t gen, counteval, nonfinite_total;
     int last_nonfinite;
+    /* termination history (pycma's rules, see ocd_cma_stop): best costs of the last hist_cap generations (newest
+     * first), every generation's best / median cost (oldest first, capped), flat-fitness run, last population range */
+    double sigma0, last_pop_range;
+    double *hist, *histbest, *histmedian, *medtmp;
+    int hist_cap, hist_len, flat;
+    int64_t nhb, hb_cap;
     int *order;
     double *z;                /* [lam, n] the normal deviates of the NEXT population, drawn ahead by ocd_cma_prepare */
     int z_ready;
@@ -169,6 +177,8 @@ static void decompose(ocd_cma *es)
         }
 }
 
+void ocd_cma_destroy(ocd_cma *es);
+
 int32_t ocd_cma_create(int32_t n, const double *x0, double sigma0, int32_t popsize, uint32_t seed, ocd_cma **out)
 {
     if (!out) return -1;
@@ -213,6 +223,15 @@ int32_t ocd_cma_create(int32_t n, const double *x0, double sigma0, int32_t popsi
     es->max_d = es->min_d = 1.0;
     es->best_f = INFINITY;
     es->fit_best = es->fit_median = es->fit_worst = NAN;
+    es->sigma0 = sigma0;
+    es->last_pop_range = INFINITY;
+    es->hist_cap = (int)floor(10.0 + 30.0 * (double)n / (double)es->lam);
+    es->hb_cap = 20000;
+    es->hist = (double *)calloc((size_t)es->hist_cap + 1, sizeof(double));
+    es->histbest = (double *)calloc((size_t)es->hb_cap, sizeof(double));
+    es->histmedian = (double *)calloc((size_t)es->hb_cap, sizeof(double));
+    es->medtmp = (double *)calloc((size_t)es->hb_cap, sizeof(double));
+    if (!es->hist || !es->histbest || !es->histmedian || !es->medtmp) { ocd_cma_destroy(es); return -1; }
     mt_seed(es, seed);
     *out = es;
     return 0;
@@ -223,6 +242,7 @@ void ocd_cma_destroy(ocd_cma *es)
     if (!es) return;
     free(es->mean);           /* the one block all double arrays live in */
     free(es->order);
+    free(es->hist); free(es->histbest); free(es->histmedian); free(es->medtmp);
     free(es);
 }
 
@@ -350,7 +370,84 @@ int32_t ocd_cma_tell(ocd_cma *es, const double *X, const double *fitness)
     es->sigma *= exp((es->cs / es->damps) * (ps_norm / es->chiN - 1));
     decompose(es);
     es->gen += 1;
+    {   /* termination history (cmaes._Termination._record) */
+        const double best = es->fit_best, worst = es->fit_worst, median = es->fit_median;
+        const int keep = es->hist_len < es->hist_cap ? es->hist_len : es->hist_cap - 1;
+        memmove(es->hist + 1, es->hist, sizeof(double) * (size_t)(keep > 0 ? keep : 0));
+        es->hist[0] = best;
+        es->hist_len = keep + 1;
+        if (es->nhb == es->hb_cap) {
+            memmove(es->histbest, es->histbest + 1, sizeof(double) * (size_t)(es->hb_cap - 1));
+            memmove(es->histmedian, es->histmedian + 1, sizeof(double) * (size_t)(es->hb_cap - 1));
+            es->nhb -= 1;
+        }
+        es->histbest[es->nhb] = best;
+        es->histmedian[es->nhb] = median;
+        es->nhb += 1;
+        es->last_pop_range = (isfinite(worst) && isfinite(best)) ? worst - best : INFINITY;
+        es->flat = (best == median) ? es->flat + 1 : 0;
+    }
     return nonfinite;
+}
+
+static int cmp_double(const void *a, const void *b)
+{
+    const double x = *(const double *)a, y = *(const double *)b;
+    return (x > y) - (x < y);
+}
+
+/* numpy.median of v[0..n): NaN if any element is NaN */
+static double median_of(ocd_cma *es, const double *v, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) { if (isnan(v[i])) return NAN; es->medtmp[i] = v[i]; }
+    qsort(es->medtmp, (size_t)n, sizeof(double), cmp_double);
+    return (n & 1) ? es->medtmp[n / 2] : 0.5 * (es->medtmp[n / 2 - 1] + es->medtmp[n / 2]);
+}
+
+/* pycma's termination rules (reward_design/cmaes.py: _Termination.stop is the same logic in Python, used by the numpy
+ * twin; tests compare the two).  opts / flags in the order: maxiter, maxfevals, tolfun, tolfunhist, tolx, tolfacupx,
+ * tolconditioncov, tolupsigma, tolstagnation, tolflatfitness.  flags[i] = 1 where the condition holds; returns how many. */
+int32_t ocd_cma_stop(ocd_cma *es, const double opts[10], int32_t flags[10])
+{
+    if (!es || !opts || !flags) return -1;
+    const int n = es->n;
+    int count = 0;
+    for (int i = 0; i < 10; ++i) flags[i] = 0;
+    if ((double)es->gen >= opts[0]) flags[0] = 1;
+    if ((double)es->counteval >= opts[1]) flags[1] = 1;
+    if (es->gen > 0) {
+        double hmax = -INFINITY, hmin = INFINITY;
+        int nfin = 0;
+        for (int i = 0; i < es->hist_len; ++i)
+            if (isfinite(es->hist[i])) { ++nfin; if (es->hist[i] > hmax) hmax = es->hist[i]; if (es->hist[i] < hmin) hmin = es->hist[i]; }
+        const double hist_range = nfin ? hmax - hmin : INFINITY;
+        double dmax = 0.0, pmax = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const double d = sqrt(es->C[i * n + i]), pc = fabs(es->pc[i]);
+            if (d > dmax) dmax = d;
+            if (pc > pmax) pmax = pc;
+        }
+        const double smax_std = es->sigma * dmax, smax_pc = es->sigma * pmax;
+        if (es->last_pop_range < opts[2] && hist_range < opts[2]) flags[2] = 1;
+        if (es->hist_len > 9 && hist_range < opts[3]) flags[3] = 1;
+        if (smax_std < opts[4] && smax_pc < opts[4]) flags[4] = 1;
+        if (smax_std > es->sigma0 * opts[5]) flags[5] = 1;
+        if (es->max_d > sqrt(opts[6]) * es->min_d) flags[6] = 1;
+        if (es->sigma / es->sigma0 > opts[7] * es->max_d) flags[7] = 1;
+        if ((double)es->flat > opts[9]) flags[9] = 1;
+        const int64_t nb = es->nhb;
+        if ((double)es->gen > (double)n * (5.0 + 100.0 / (double)es->lam) && nb > 100) {
+            const double a = opts[8] / 5.0 / 2.0, b = (double)nb / 10.0;
+            const int64_t ell = (int64_t)(a > b ? a : b);
+            if (2 * ell < nb && ell > 0) {
+                const double m_new = median_of(es, es->histmedian + (nb - ell), ell), m_old = median_of(es, es->histmedian, ell);
+                const double b_new = median_of(es, es->histbest + (nb - ell), ell), b_old = median_of(es, es->histbest, ell);
+                if (m_new >= m_old && b_new >= b_old) flags[8] = 1;
+            }
+        }
+    }
+    for (int i = 0; i < 10; ++i) count += flags[i];
+    return count;
 }
 
 int32_t ocd_cma_state(const ocd_cma *es, double *mean, double *sigma, double *C, double *best_x, double *best_f,
@@ -431,6 +528,80 @@ int32_t ocd_normalise_weights(const double *W, int64_t P, int64_t D, int32_t var
             for (int64_t i = 0; i < D; ++i) row[i] = row[i] / nrm;
         }
         for (int64_t i = 0; i < D; ++i) out[p * D + i] = (float)row[i];
+    }
+    return 0;
+}
+
+/* ---- whole generations in native code ------------------------------------------------------------------------------
+ * ask -> normalise into the pinned rows the kernel reads -> launch (through the caller's function pointer: this
+ * library stays free of HIP) -> draw the next population's deviates and write the history rows while the GPU works ->
+ * wait -> float64 reduction -> tell -> termination test, generation after generation, without returning to Python.
+ * Around a 1.6 ms kernel the Python loop of MPC_ORD.optimize_cmaes costs ~45 us per generation in interpreter and
+ * ctypes overhead; this one costs what the arithmetic and the launch cost.  Same functions, same order, same bits. */
+static double now_s(void)
+{
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+
+static void row_normalise_once(const double *x, int n, int variant, double *out)
+{
+    double dot = 0.0;
+    if (variant == 1) for (int i = 0; i < n; ++i) dot = __builtin_fma(x[i], x[i], dot);
+    else for (int i = 0; i < n; ++i) dot = dot + x[i] * x[i];
+    const double nrm = sqrt(dot);
+    for (int i = 0; i < n; ++i) out[i] = x[i] / nrm;
+}
+
+int32_t ocd_cma_run(ocd_cma *es, const ocd_cma_run_args *a, int64_t *generations_done, int32_t stop_flags[10],
+                    int32_t *pending_nan)
+{
+    if (!es || !a || !generations_done || !stop_flags || !pending_nan) return -1;
+    if (!a->rollout || !a->sync || !a->w_pinned || !a->ret_pinned || !a->X || !a->cost || a->N < 1 || a->S < 1 ||
+        a->max_generations < 0 || a->normalise_variant < 0 || a->normalise_variant > 1) return -1;
+    const int n = es->n, lam = es->lam;
+    const int64_t E = (int64_t)lam * a->N * a->S;
+    *generations_done = 0;
+    *pending_nan = 0;
+    for (int i = 0; i < 10; ++i) stop_flags[i] = 0;
+    for (int64_t g = 0; g < a->max_generations; ++g) {
+        double *sg = a->seconds ? a->seconds + 8 * g : NULL;
+        const double t0 = now_s();
+        if (ocd_cma_ask(es, a->X) != 0) return -1;
+        const double t1 = now_s();
+        if (ocd_normalise_weights(a->X, lam, n, a->normalise_variant, a->w_pinned) != 0) return -1;
+        const double t2 = now_s();
+        const int32_t st = a->rollout(a->scn, a->init_dev, a->w_pinned, lam, a->N, 0, E, a->ret_pinned, NULL, NULL, a->stream);
+        if (st != 0) return st < 0 ? st : -1;
+        const double t3 = now_s();
+        /* while the GPU works: the next population's deviates, this generation's history rows (mpc_ord.py:120,146) */
+        ocd_cma_prepare(es);
+        if (a->hist_w)
+            for (int k = 0; k < lam; ++k)
+                row_normalise_once(a->X + (size_t)k * n, n, a->normalise_variant, a->hist_w + ((size_t)g * lam + k) * n);
+        const double t4 = now_s();
+        if (a->sync(a->stream) != 0) return -1;
+        const double t5 = now_s();
+        if (ocd_fitness_from_returns(a->ret_pinned, lam, a->N, a->S, a->cost) != 0) return -1;
+        int any_nan = 0;
+        for (int k = 0; k < lam; ++k) any_nan |= isnan(a->cost[k]);
+        if (a->hist_cost) memcpy(a->hist_cost + (size_t)g * lam, a->cost, sizeof(double) * (size_t)lam);
+        const double t6 = now_s();
+        if (sg) { sg[1] = t1 - t0; sg[2] = t2 - t1; sg[3] = t3 - t2; sg[4] = t4 - t3; sg[5] = t5 - t4; sg[6] = t6 - t5; sg[7] = 0.0; sg[0] = t6 - t0; }
+        if (any_nan) {                       /* pycma redraws NaN candidates: the caller does that, then tells */
+            *pending_nan = 1;
+            *generations_done = g;           /* generation g is evaluated (X, cost, history row written) but not told */
+            return 0;
+        }
+        const int32_t nonfinite = ocd_cma_tell(es, a->X, a->cost);
+        if (nonfinite < 0) return -1;
+        if (a->nonfinite) a->nonfinite[g] = nonfinite;
+        const int32_t stops = ocd_cma_stop(es, a->stop_opts, stop_flags);
+        const double t7 = now_s();
+        if (sg) { sg[7] = t7 - t6; sg[0] = t7 - t0; }
+        *generations_done = g + 1;
+        if (stops > 0) return 0;
     }
     return 0;
 }

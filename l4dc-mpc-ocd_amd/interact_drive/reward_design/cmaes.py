@@ -254,6 +254,19 @@ class CMAES(_Termination):
 _CMA_LIB = None
 _D = C.POINTER(C.c_double)
 
+# the order of opts / flags of ocd_cma_stop (include/ocd_cma.h)
+STOP_NAMES = ("maxiter", "maxfevals", "tolfun", "tolfunhist", "tolx", "tolfacupx", "tolconditioncov", "tolupsigma",
+              "tolstagnation", "tolflatfitness")
+
+
+class RunArgs(C.Structure):
+    """struct ocd_cma_run_args (include/ocd_cma.h)."""
+    _fields_ = [("scn", C.c_void_p), ("init_dev", C.c_void_p), ("N", C.c_int64), ("S", C.c_int64),
+                ("w_pinned", C.c_void_p), ("ret_pinned", C.c_void_p), ("stream", C.c_void_p),
+                ("rollout", C.c_void_p), ("sync", C.c_void_p), ("normalise_variant", C.c_int32), ("reserved", C.c_int32),
+                ("max_generations", C.c_int64), ("stop_opts", C.c_double * 10), ("X", C.c_void_p), ("cost", C.c_void_p),
+                ("hist_w", C.c_void_p), ("hist_cost", C.c_void_p), ("seconds", C.c_void_p), ("nonfinite", C.c_void_p)]
+
 
 def load_cma_library():
     """dlopen csrc/libocd_cma.so (built by `make -C csrc`, plain C) and bind include/ocd_cma.h."""
@@ -297,6 +310,10 @@ def load_cma_library():
     lib.ocd_cma_abi_version.argtypes = []
     lib.ocd_normalise_weights.restype = C.c_int32
     lib.ocd_normalise_weights.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]
+    lib.ocd_cma_stop.restype = C.c_int32
+    lib.ocd_cma_stop.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ocd_cma_run.restype = C.c_int32
+    lib.ocd_cma_run.argtypes = [C.c_void_p, C.POINTER(RunArgs), C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int32)]
     lib.ocd_cma_state.restype = C.c_int32
     lib.ocd_cma_state.argtypes = [C.c_void_p, _D, _D, _D, _D, _D, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _D]
     lib.ocd_fitness_from_returns.restype = C.c_int32
@@ -344,6 +361,8 @@ class NativeCMAES(_Termination):
         self._f_ptr = self._f.ctypes.data
         self._ss = np.empty(13, dtype=np.float64)
         self._ss_ptr = self._ss.ctypes.data
+        self._opts_c = np.empty(10, dtype=np.float64)
+        self._flags_c = np.zeros(10, dtype=np.int32)
         self._init_termination(sigma0)
 
     def __del__(self):
@@ -377,10 +396,46 @@ class NativeCMAES(_Termination):
         nonfinite = self.lib.ocd_cma_tell(self._h, self._X_ptr, self._f_ptr)
         if nonfinite < 0:
             raise RuntimeError("ocd_cma_tell failed")
-        self.lib.ocd_cma_stop_state(self._h, self._ss_ptr)
-        ss = self._ss
-        self._record(ss[5], ss[6], ss[7], nonfinite)
+        self.last_nonfinite = nonfinite                            # (the termination history lives in the C state)
+        self.nonfinite_total += nonfinite
         return nonfinite
+
+    def _stop_opts(self, overrides):
+        o = dict(self.opts)
+        for k, v in overrides.items():
+            if v is not None:
+                if k not in o:
+                    raise TypeError(f"unknown termination option {k!r}")
+                o[k] = v
+        return o
+
+    def stop(self, tolfun=None, tolx=None, maxiter=None, last_fitness=None, **overrides):
+        """pycma's termination rules, evaluated by csrc/ocd_cma.c:ocd_cma_stop on the history ocd_cma_tell keeps (the
+        numpy twin runs the same rules in Python: _Termination.stop).  {} = go on."""
+        o = self._stop_opts(dict(tolfun=tolfun, tolx=tolx, maxiter=maxiter, **overrides))
+        for i, k in enumerate(STOP_NAMES):
+            self._opts_c[i] = o[k]
+        n = self.lib.ocd_cma_stop(self._h, self._opts_c.ctypes.data, self._flags_c.ctypes.data)
+        if n < 0:
+            raise RuntimeError("ocd_cma_stop failed")
+        return {k: o[k] for i, k in enumerate(STOP_NAMES) if self._flags_c[i]} if n else {}
+
+    def run(self, args: "RunArgs", overrides):
+        """ocd_cma_run: generations in native code until a termination rule holds, `args.max_generations` are done, or
+        a generation is left evaluated-but-not-told because a cost is NaN.  Returns (generations told, stop dict,
+        pending_nan)."""
+        o = self._stop_opts(overrides)
+        for i, k in enumerate(STOP_NAMES):
+            args.stop_opts[i] = o[k]
+        args.X, args.cost = self._X_ptr, self._f_ptr
+        done, pending = C.c_int64(0), C.c_int32(0)
+        st = self.lib.ocd_cma_run(self._h, C.byref(args), C.byref(done), self._flags_c.ctypes.data, C.byref(pending))
+        if st != 0:
+            raise RuntimeError(f"ocd_cma_run -> {st}")
+        self.lib.ocd_cma_stop_state(self._h, self._ss_ptr)
+        self.last_nonfinite, self.nonfinite_total = int(self._ss[8]), int(self._ss[9])
+        why = {k: o[k] for i, k in enumerate(STOP_NAMES) if self._flags_c[i]}
+        return int(done.value), why, bool(pending.value)
 
     def finish_tell(self):                                         # (the numpy twin defers work; nothing to do here)
         pass

@@ -326,24 +326,28 @@ class MPC_ORD:
         self._eng_fixed = self._engine()                           # world and car do not change inside the loop
         self._defer_history = self.save_path is None               # (a saved history must be complete at every dump)
         self._overlap_hooks = [es.prepare]                          # the next population's deviates, while the GPU works
+        overrides = dict(maxiter=maxiter, maxfevals=maxfevals, **(termination or {}))
         try:
-            while True:
-                t0 = time.perf_counter()                           # a generation: ask, fitness of the population, tell
-                X = es.ask()
-                t1 = self._tick("ask", t0)
-                f = self.eval_population(X)
-                if np.isnan(f).any():
-                    f = self._resample_nan(es, X, f)
-                t2 = time.perf_counter()
-                self.fitness_seconds.append(t2 - t1)
-                es.tell(X, f)
-                t3 = self._tick("tell", t2)
-                why = es.stop(maxiter=maxiter, maxfevals=maxfevals, **(termination or {}))
-                self._tick("stop", t3)
-                self.generation_seconds.append(time.perf_counter() - t0)     # ask ... termination test
-                if why:
-                    self.stop_reason = why
-                    break
+            if self._native_loop_possible(es):
+                self._optimize_cmaes_native(es, overrides)
+            else:
+                while True:
+                    t0 = time.perf_counter()                       # a generation: ask, fitness of the population, tell
+                    X = es.ask()
+                    t1 = self._tick("ask", t0)
+                    f = self.eval_population(X)
+                    if np.isnan(f).any():
+                        f = self._resample_nan(es, X, f)
+                    t2 = time.perf_counter()
+                    self.fitness_seconds.append(t2 - t1)
+                    es.tell(X, f)
+                    t3 = self._tick("tell", t2)
+                    why = es.stop(**overrides)
+                    self._tick("stop", t3)
+                    self.generation_seconds.append(time.perf_counter() - t0)     # ask ... termination test
+                    if why:
+                        self.stop_reason = why
+                        break
         finally:                                                   # also on an exception or Ctrl-C inside a long run
             self._eng_fixed = None
             self._init_np_cache = None
@@ -354,6 +358,83 @@ class MPC_ORD:
         self.done = True
         self.es = es
         return es.best_x
+
+    # ------------------------------------------------------------------ generations in native code
+    def _native_loop_possible(self, es):
+        """One process, no history file to keep complete after every evaluation, and a native normalisation that
+        reproduces numpy's on this machine: then whole generations run inside csrc/ocd_cma.c (ocd_cma_run)."""
+        import torch.distributed as dist
+        from ...scenarios import _native_normalise_variant
+        if self.save_path is not None or getattr(self, "force_python_loop", False):
+            return False
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return False
+        return hasattr(es, "run") and _native_normalise_variant(self.weight_dim) is not None
+
+    def _optimize_cmaes_native(self, es, overrides, chunk=64):
+        """The loop of optimize_cmaes through ocd_cma_run: ask, normalise into the pinned rows, launch, (next deviates
+        and history rows while the GPU works,) wait, reduce, tell, termination test -- generation after generation
+        without returning to the interpreter; Python only books the results every `chunk` generations and handles the
+        rare generation with a NaN cost (pycma's rejection sampling) itself."""
+        import ctypes as C
+        import torch
+        from .cmaes import RunArgs
+        from ...scenarios import _native_normalise_variant
+        eng = self._eng_fixed
+        with torch.cuda.device(eng.device):
+            init = self._init_key_array(self.init_car_states)
+            P, N, S, D = es.lam, init.shape[0], self.num_samples, self.weight_dim
+            E = P * N * S
+            init_dev = self._init_states_dev(eng, init)
+            st = self._staging(eng, P, N, S, D, E)
+            hist_w = np.empty((chunk, P, D), dtype=np.float64)
+            hist_c = np.empty((chunk, P), dtype=np.float64)
+            secs = np.zeros((chunk, 8), dtype=np.float64)
+            nonf = np.zeros(chunk, dtype=np.int32)
+            a = RunArgs()
+            a.scn, a.init_dev, a.N, a.S = eng._h.value, init_dev.data_ptr(), N, S
+            a.w_pinned, a.ret_pinned = st["w_ptr"], st["ret_host_ptr"]
+            a.stream = torch.cuda.current_stream().cuda_stream
+            a.rollout = C.cast(eng.lib.ocd_rollout_episodes, C.c_void_p).value
+            a.sync = C.cast(eng.lib.ocd_stream_synchronize, C.c_void_p).value
+            a.normalise_variant = _native_normalise_variant(D)
+            a.max_generations = chunk
+            a.hist_w, a.hist_cost = hist_w.ctypes.data, hist_c.ctypes.data
+            a.seconds, a.nonfinite = secs.ctypes.data, nonf.ctypes.data
+            names = ("ask", "normalise", "launch", "overlapped_bookkeeping", "kernel_gather_readback", "reduce", "tell")
+            toggles = hasattr(self.world, "unlucky_car_idx") and (E % 2)
+
+            def book(g0, g1):                                      # generations [g0, g1) of this call's buffers
+                for g in range(g0, g1):
+                    self.history.extend(zip(hist_w[g].copy(), -hist_c[g]))
+                    self.iter += P
+                    if toggles:                                    # world.reset() side effects, as _returns keeps them
+                        self.world.unlucky_car_idx = 2 if self.world.unlucky_car_idx == 1 else 1
+
+            while True:
+                done, why, pending = es.run(a, overrides)
+                book(0, done)
+                for g in range(done):
+                    self.generation_seconds.append(float(secs[g, 0]))
+                    self.fitness_seconds.append(float(secs[g, 2:7].sum()))
+                    self.n_nonfinite.append(int(nonf[g]))
+                    for k, name in enumerate(names):
+                        self.host_split.setdefault(name, []).append(float(secs[g, 1 + k]))
+                if pending:                                        # generation `done` is evaluated, not told: redraw its NaN
+                    t0 = time.perf_counter()
+                    book(done, done + 1)
+                    f = es._f.copy()
+                    self.n_nonfinite.append(P - int(np.isfinite(f).sum()))
+                    f = self._resample_nan(es, es._X, f)
+                    self._flush_history()                          # (the redrawn candidates' entries, in evaluation order)
+                    es.tell(es._X, f)
+                    why = es.stop(**overrides)
+                    self.generation_seconds.append(float(secs[done, 0]) + time.perf_counter() - t0)
+                    self.fitness_seconds.append(self.generation_seconds[-1])
+                if why:
+                    self.stop_reason = why
+                    break
+            self.last_returns = st["ret_np"].copy().reshape(P, N, S)
 
     def _resample_nan(self, es, X, f):
         """pycma's rejection sampling (ask_and_eval behind mpc_ord.py:41): redraw and re-evaluate the candidates

@@ -499,3 +499,97 @@ def test_row_dots_is_the_per_row_blas_dot():
         del sc._ROW_DOTS_BATCHED_OK[7]
     for row in rng.standard_normal((50, 7)):
         assert np.array_equal(sc.planner_weights_fp32_batch(row[None])[0], sc.planner_weights_fp32(row))
+
+
+def test_native_generation_loop_is_the_python_loop():
+    """csrc/ocd_cma.c:ocd_cma_run (whole generations without returning to the interpreter: what MPC_ORD.optimize_cmaes
+    runs in one process) against the same generations driven call by call from Python -- same population, costs,
+    history rows, termination and state; a NaN cost hands the generation back untold.  The episode launch is a function
+    pointer: here a Python callback that scores the normalised fp32 weights it finds in the "pinned" rows."""
+    import ctypes as C
+    from l4dc_mpc_ocd_amd.interact_drive.reward_design.cmaes import NativeCMAES, RunArgs, fitness_from_returns_native
+    from l4dc_mpc_ocd_amd.scenarios import _native_normalise_variant, planner_weights_fp32_batch
+    D, P, N, S = 7, 16, 3, 2
+    variant = _native_normalise_variant(D)
+    if variant is None:
+        pytest.skip("no native summation order reproduces numpy's dot on this machine")
+    target = np.linspace(-0.5, 0.4, D).astype(np.float32)
+    nan_at = {"calls": 0, "when": 5}
+
+    def score(w32):                                    # returns [P, N, S] fp32 from the fp32 planner weights
+        base = -np.sum((w32 - target) ** 2, axis=1, dtype=np.float32)
+        r = (base[:, None, None] * (1.0 + 0.1 * np.arange(N, dtype=np.float32)[None, :, None])
+             - 0.01 * np.arange(S, dtype=np.float32)[None, None, :]).astype(np.float32)
+        return r
+
+    w_pinned = np.zeros((P, D), dtype=np.float32)
+    ret_pinned = np.zeros(P * N * S, dtype=np.float32)
+    ROLL = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+    SYNC = C.CFUNCTYPE(C.c_int32, C.c_void_p)
+
+    def rollout(scn, init, w, p, n, e0, e1, ret, traj, ctrl, stream):
+        assert (p, n, e0, e1) == (P, N, 0, P * N * S) and w == w_pinned.ctypes.data and ret == ret_pinned.ctypes.data
+        nan_at["calls"] += 1
+        r = score(w_pinned)
+        if nan_at["calls"] == nan_at["when"]:
+            r[3, 1, 0] = np.nan
+        ret_pinned[:] = r.reshape(-1)
+        return 0
+
+    roll_c, sync_c = ROLL(rollout), SYNC(lambda stream: 0)
+    x0 = [0.3, -0.2, 0.1, 0.0, 0.2, -0.1, 0.4]
+    a = NativeCMAES(x0, 0.2, popsize=P, seed=9)
+    chunk = 7
+    hist_w, hist_c = np.empty((chunk, P, D)), np.empty((chunk, P))
+    secs, nonf = np.zeros((chunk, 8)), np.zeros(chunk, dtype=np.int32)
+    args = RunArgs()
+    args.N, args.S = N, S
+    args.w_pinned, args.ret_pinned = w_pinned.ctypes.data, ret_pinned.ctypes.data
+    args.rollout, args.sync = C.cast(roll_c, C.c_void_p).value, C.cast(sync_c, C.c_void_p).value
+    args.normalise_variant, args.max_generations = variant, chunk
+    args.hist_w, args.hist_cost, args.seconds, args.nonfinite = (hist_w.ctypes.data, hist_c.ctypes.data, secs.ctypes.data,
+                                                              nonf.ctypes.data)
+    native_hist, gens = [], 0
+    overrides = dict(maxiter=23)
+    while True:
+        done, why, pending = a.run(args, overrides)
+        for g in range(done):
+            native_hist.extend(zip(hist_w[g].copy(), -hist_c[g]))
+        gens += done
+        assert np.all(secs[:done, 0] > 0) and np.all(nonf[:done] == 0)
+        if pending:                                    # generation `done` came back evaluated but untold
+            assert np.isnan(a._f).sum() == 1 and np.isnan(hist_c[done]).sum() == 1
+            native_hist.extend(zip(hist_w[done].copy(), -hist_c[done]))
+            f = a._f.copy()
+            rows = np.nonzero(np.isnan(f))[0]
+            Xr = a.resample(rows)
+            f[rows] = fitness_from_returns_native(score(planner_weights_fp32_batch(Xr)).reshape(-1), len(rows), N, S)
+            a.tell(a._X, f)
+            gens += 1
+            why = a.stop(**overrides)
+        if why:
+            break
+    assert why == {"maxiter": 23} and gens == 23 and a.gen == 23
+    # the same run, call by call
+    b = NativeCMAES(x0, 0.2, popsize=P, seed=9)
+    py_hist = []
+    for g in range(23):
+        X = b.ask()
+        w32 = planner_weights_fp32_batch(X)
+        r = score(w32)
+        if g + 1 == nan_at["when"]:
+            r[3, 1, 0] = np.nan
+        f = fitness_from_returns_native(r.reshape(-1), P, N, S).copy()
+        py_hist.extend(zip(X / np.sqrt(scenarios.row_dots(X))[:, None], -f))
+        b.prepare()                                    # (the native loop draws the next deviates while the GPU works)
+        if np.isnan(f).any():
+            rows = np.nonzero(np.isnan(f))[0]
+            Xr = b.resample(rows)
+            f[rows] = fitness_from_returns_native(score(planner_weights_fp32_batch(Xr)).reshape(-1), len(rows), N, S)
+        b.tell(X, f)
+        assert (b.stop(**overrides) != {}) == (g == 22)
+    assert np.array_equal(a.mean, b.mean) and a.sigma == b.sigma and np.array_equal(a.C, b.C) and a.best_f == b.best_f
+    assert len(native_hist) == len(py_hist) == 23 * P
+    for (wa, ra), (wb, rb) in zip(native_hist, py_hist):
+        assert np.array_equal(wa, wb) and (ra == rb or (np.isnan(ra) and np.isnan(rb)))
