@@ -183,6 +183,9 @@ def main():
     ap.add_argument("--force-collective", action="store_true",
                     help="N=1: create a one-rank RCCL group and run the all-gather of the returns inside every timed "
                          "step, exactly as N ranks do")
+    ap.add_argument("--python-steps", action="store_true",
+                    help="one process: drive the timed steps from Python (one C-ABI call, one event wait, one native "
+                         "reduction per step) instead of the native step loop")
     ap.add_argument("--plumbing-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     args.config = int(args.config) if args.config.isdigit() else args.config
@@ -324,8 +327,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            fit = generation()
+        if sharded or args.python_steps or e0 != 0:          # (a rank's block of a larger population: Python steps)
+            for _ in range(steps):
+                fit = generation()
+        else:
+            # one process: the K steps run as the product runs a generation's fitness inside its native CMA-ES loop
+            # (csrc/ocd_cma.c: ocd_eval_generations -- the same launch, stream wait and float64 reduction through the
+            # same entry points, without the interpreter between steps)
+            import ctypes as C
+            from l4dc_mpc_ocd_amd.interact_drive.reward_design.cmaes import RunArgs, load_cma_library
+            ra = RunArgs()
+            ra.scn, ra.init_dev, ra.N, ra.S = handle.value, init_ptr, N, S
+            ra.w_pinned, ra.ret_pinned, ra.stream = w_ptr, out_ptr, stream_ptr
+            ra.rollout = C.cast(eng.lib.ocd_rollout_episodes, C.c_void_p).value
+            ra.sync = C.cast(eng.lib.ocd_stream_synchronize, C.c_void_p).value
+            st_ = load_cma_library().ocd_eval_generations(C.byref(ra), hi - lo, steps, cost_buf.ctypes.data, None)
+            if st_ != 0:
+                raise SystemExit(f"ocd_eval_generations -> {st_}: {eng.lib.ocd_last_error().decode()}")
+            fit = cost_buf
         torch.cuda.synchronize()
         if sharded:
             dist.barrier()

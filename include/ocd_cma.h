@@ -105,6 +105,12 @@ typedef struct ocd_cma_run_args {
 int32_t ocd_cma_run(ocd_cma *es, const ocd_cma_run_args *a, int64_t *generations_done, int32_t stop_flags[10],
                     int32_t *pending_nan);
 
+/* K fitness evaluations of one fixed population back to back -- launch (a->rollout on the P rows of a->w_pinned, taken
+ * as they are), wait (a->sync), float64 reduction into cost_out [P] -- without the interpreter between them: what a
+ * generation of ocd_cma_run spends outside ask / tell, and what bench.py times as its step in one process.  Uses scn,
+ * init_dev, N, S, w_pinned, ret_pinned, stream, rollout, sync of the argument block. */
+int32_t ocd_eval_generations(const ocd_cma_run_args *a, int64_t P, int64_t K, double *cost_out, double *seconds_out);
+
 /* W [P, D] float64 candidate weights -> out [P, D] fp32 as the planning car gets them: three float64 normalisations
  * (mpc_ord.py:120,71; linear_reward_car.py:45-47) and the fp32 cast.  `variant` names the summation order of the
  * dot product behind np.linalg.norm on this machine (0: mul + add left to right, 1: fma left to right); the binding

@@ -606,3 +606,23 @@ int32_t ocd_cma_run(ocd_cma *es, const ocd_cma_run_args *a, int64_t *generations
     return 0;
 }
 
+/* K fitness evaluations of one fixed population, back to back: launch, wait, float64 reduction -- the part of a
+ * generation that bench.py times as its "step", through the same function pointers and without the interpreter between
+ * steps.  The rows of a->w_pinned are evaluated as they are (already normalised fp32); cost_out [P] holds the last
+ * step's costs; seconds_out (or NULL) the wall time of the K steps as this loop saw it. */
+int32_t ocd_eval_generations(const ocd_cma_run_args *a, int64_t P, int64_t K, double *cost_out, double *seconds_out)
+{
+    if (!a || !a->rollout || !a->sync || !a->w_pinned || !a->ret_pinned || !cost_out || P < 1 || K < 0 || a->N < 1 || a->S < 1)
+        return -1;
+    const int64_t E = P * a->N * a->S;
+    const double t0 = now_s();
+    for (int64_t k = 0; k < K; ++k) {
+        const int32_t st = a->rollout(a->scn, a->init_dev, a->w_pinned, P, a->N, 0, E, a->ret_pinned, NULL, NULL, a->stream);
+        if (st != 0) return st < 0 ? st : -1;
+        if (a->sync(a->stream) != 0) return -1;
+        if (ocd_fitness_from_returns(a->ret_pinned, P, a->N, a->S, cost_out) != 0) return -1;
+    }
+    if (seconds_out) *seconds_out = now_s() - t0;
+    return 0;
+}
+

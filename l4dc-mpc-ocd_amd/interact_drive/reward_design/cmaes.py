@@ -312,6 +312,8 @@ def load_cma_library():
     lib.ocd_normalise_weights.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]
     lib.ocd_cma_stop.restype = C.c_int32
     lib.ocd_cma_stop.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ocd_eval_generations.restype = C.c_int32
+    lib.ocd_eval_generations.argtypes = [C.POINTER(RunArgs), C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_double)]
     lib.ocd_cma_run.restype = C.c_int32
     lib.ocd_cma_run.argtypes = [C.c_void_p, C.POINTER(RunArgs), C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int32)]
     lib.ocd_cma_state.restype = C.c_int32

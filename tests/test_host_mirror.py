@@ -209,7 +209,8 @@ def test_cma_library_exports_what_its_header_declares():
     names = re.findall(r"^\w[\w\s\*]*?\b(ocd_\w+)\s*\(", open(os.path.join(root, "include", "ocd_cma.h")).read(), re.M)
     assert set(names) >= {"ocd_cma_create", "ocd_cma_destroy", "ocd_cma_ask", "ocd_cma_tell", "ocd_cma_prepare",
                           "ocd_cma_state", "ocd_cma_popsize", "ocd_fitness_from_returns", "ocd_cma_resample",
-                          "ocd_cma_stop_state", "ocd_cma_abi_version", "ocd_normalise_weights"}
+                          "ocd_cma_stop_state", "ocd_cma_abi_version", "ocd_normalise_weights", "ocd_cma_stop", "ocd_cma_run",
+                          "ocd_eval_generations"}
     for n in names:
         assert isinstance(getattr(lib, n), ctypes._CFuncPtr), n
 
