@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Exhaustive parity: EVERY episode of BASELINE configs 2-5, HIP path vs CPU oracle, bit for bit.
+"""Exhaustive parity: EVERY episode of BASELINE configs 2-5, HIP path vs CPU oracle, bit for bit -- the returns and
+(unless --no-traj) every world state and every applied control of every episode.
 (The regular GPU suite checks config 3 completely and configs 4/5 on samples; this is the long form.)
 usage: python tools/verify_all_configs.py [--configs 2,3,4,5] [--threads 16]"""
 import argparse
@@ -21,6 +22,7 @@ def main():
     ap.add_argument("--scan-mode", type=int, default=0, help="force a kernel variant (ocd_scenario_set_option scan_mode)")
     ap.add_argument("--split", type=int, default=8, help="also run every config as this many equal episode blocks (the "
                     "per-GPU shares of a strong split: other launch shapes, other kernel builds); 0 = whole batch only")
+    ap.add_argument("--no-traj", action="store_true", help="compare the returns only")
     a = ap.parse_args()
     import oracle_lib
     from l4dc_mpc_ocd_amd import scenarios
@@ -33,18 +35,29 @@ def main():
         t0 = time.perf_counter()
         eng = Engine(scn, "cuda:0")
         eng.set_option("scan_mode", a.scan_mode)
-        got = eng.rollout(inits, w32)["returns"]
+        full = eng.rollout(inits, w32, want_traj=not a.no_traj)
+        got = full["returns"]
         ll = eng.last_launch()
         whole_tag = f"{ll['mapping']}" + (f" S={ll['chunk']}" if ll["chunk"] else "") + f" x{ll['trajectories_per_wavefront']} build={ll['build_wavefronts_per_simd']}"
         t1 = time.perf_counter()
         ref = np.empty_like(got)
         E = got.size
         chunk = 2048
+        traj_same = ctrl_same = n_traj = n_ctrl = 0
         for b in range(0, E, chunk):                       # chunked so that progress is visible
             e = min(E, b + chunk)
-            ref[b:e] = orc.rollout(scn.desc, inits, w32, ep_begin=b, ep_end=e, n_threads=a.threads)["returns"]
+            r = orc.rollout(scn.desc, inits, w32, ep_begin=b, ep_end=e, n_threads=a.threads, want_traj=not a.no_traj)
+            ref[b:e] = r["returns"]
+            if not a.no_traj:
+                gt, gc = full["traj"][b:e], full["ctrl"][b:e]
+                traj_same += int(((gt == r["traj"]) | (np.isnan(gt) & np.isnan(r["traj"]))).sum()); n_traj += gt.size
+                ctrl_same += int(((gc == r["ctrl"]) | (np.isnan(gc) & np.isnan(r["ctrl"]))).sum()); n_ctrl += gc.size
             print(f"  cfg{cfg}: oracle {e}/{E}", flush=True)
         t2 = time.perf_counter()
+        if not a.no_traj:
+            print(f"cfg{cfg} {scn.name}: world states identical {traj_same}/{n_traj} floats, applied controls identical "
+                  f"{ctrl_same}/{n_ctrl} floats", flush=True)
+            ok &= traj_same == n_traj and ctrl_same == n_ctrl
         same = (got == ref) | (np.isnan(got) & np.isnan(ref))
         nonfinite = int((~np.isfinite(ref)).sum())
         print(f"cfg{cfg} {scn.name} H={scn.desc.horizon} [{whole_tag}]: {E} episodes, identical {int(same.sum())}/{E} "
