@@ -113,7 +113,7 @@ mpc_chunk_kernel(const KernelParams p)
         for (int k = 0; k < OCD_MAX_FEATURES; ++k) w[k] = (wp && k < D) ? wp[k] : 0.0f;
         tp_idx = p.sample_fixed;
     }
-    const LaneGradConst<L> lgc = lane_grad_const<L>(w);
+    const LaneGradConst<L> lgc = lane_grad_const<L>(w, d);
     float wd[OCD_MAX_FEATURES];
 #pragma unroll
     for (int k = 0; k < OCD_MAX_FEATURES; ++k) wd[k] = d.designer_weights[k];
@@ -358,16 +358,21 @@ mpc_chunk_kernel(const KernelParams p)
                         multi_c |= (mj & mc_any);
                         mc_any |= mj;
                     }
+                    // a fence lane beyond the guard of the shortened reciprocals (LaneGradConst::x_hi): the full divisions
+                    const unsigned long long beyond = __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(xn) < lgc.x_hi)) & mf;
                     OCD_STAMP(4);                          // choice of the evaluation
-                    if (__builtin_expect((multi_f | multi_c) != 0ull, 0)) {
+                    if (__builtin_expect((multi_f | multi_c | beyond) != 0ull, 0)) {
                         if (multi_c != 0ull)
                             rw[s] = reward_every<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], q[s], pkc);
-                        else
+                        else if (multi_f != 0ull)
                             rw[s] = reward_fc<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], nc, q[s], pkc);
+                        else
+                            rw[s] = reward_one<NO, L, GRAD, false>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], nc, nf, true, true,
+                                                                   q[s], pkc, lgc, lm);
                         OCD_STAMP(5); OCD_STAMP_COUNT(12);
                     } else {
-                        rw[s] = reward_one<NO, L, GRAD, false>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], nc, nf, true, true,
-                                                               q[s], pkc, lgc, lm);
+                        rw[s] = reward_one<NO, L, GRAD, false, false, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], nc, nf, true,
+                                                                            true, q[s], pkc, lgc, lm);
                         OCD_STAMP(6); OCD_STAMP_COUNT(13);
                     }
                     if constexpr (GRAD) {

@@ -624,13 +624,27 @@ __device__ __forceinline__ float reward_every(const ocd_scenario_desc &d, const 
 // Lane-feature gradient factors of one trajectory (its weights are fixed for the whole episode): the chain
 //   g = w_l (+ w_min when lane l is the sole minimum) ; g_d2 = g * 10 ; (g_d2 * 2)
 // of the backward pass evaluated once, outside the SGD loop (same operations, same order, hoisted).
+// x_hi: the guard of reward_one's FASTDIV form (recip_pair_guarded, ocd_devmath.h) -- a pass may use it if every live
+// fence lane has |x| < x_hi (the callers test that; 0 = never).  The denominators of -1/u on a fence lane are
+// u1 = shape * xd and u2 = shape * (xd2 > 0 ? xd2 : 0.01) with xd = |x| - fence_lo > 0 and xd2 = width - xd.  Two floats
+// that differ differ by a unit in the last place at least: xd >= fence_lo * 2^-24, and xd2 >= width * 2^-25 where it is
+// positive (and xd2 <= width).  With shape * fence_lo >= 2^-5, 2^-5 <= shape * width <= 2^39 and
+// 2^-31 <= shape * 0.01 <= 2^39 (checked here, once per kernel) every such denominator is >= 2^-31 and u2 <= 2^39;
+// u1 <= shape * |x| < 2^38 (1 + 2^-22) is the per-pass test.  On the other lanes the denominators are 1 - xc^2 with
+// xc^2 < 1 in fp32, i.e. in [2^-24, 1].
 template <int L>
-struct LaneGradConst { float g0[L > 0 ? L : 1], g1[L > 0 ? L : 1]; };
+struct LaneGradConst { float g0[L > 0 ? L : 1], g1[L > 0 ? L : 1]; float x_hi; };
 
 template <int L>
-__device__ __forceinline__ LaneGradConst<L> lane_grad_const(const float (&w)[OCD_MAX_FEATURES])
+__device__ __forceinline__ LaneGradConst<L> lane_grad_const(const float (&w)[OCD_MAX_FEATURES], const ocd_scenario_desc &d)
 {
     LaneGradConst<L> c;
+    {
+        const float a = d.fence_shape * d.fence_lo, b = d.fence_shape * d.fence_width, k = d.fence_shape * (0.0f + 0.01f);
+        const float lo5 = 0.03125f, hi39 = 549755813888.0f, lo31 = 4.656612873077392578125e-10f;
+        const bool ok = a >= lo5 && b >= lo5 && b <= hi39 && k >= lo31 && k <= hi39;      // (false for NaN)
+        c.x_hi = ok ? 274877906944.0f / d.fence_shape : 0.0f;
+    }
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         c.g0[l] = (w[1 + l] * 10.0f) * 2.0f;
@@ -661,7 +675,8 @@ __device__ __forceinline__ LaneGradConst<L> lane_grad_const(const float (&w)[OCD
 // in nearly every pass: the skips only help where several wavefronts share a SIMD.
 // PRE0 (GRAD only): the caller has filled q.qv / q.qth with the target-speed feature's adjoint already (the
 // V_ROW build computes it in the hazard slots of the position recurrence, ocd_chains.h).
-template <int NO, int L, bool GRAD, bool SUB = true, bool PRE0 = false>
+// FASTDIV (GRAD only): precondition -- every live fence lane has |x| < lgc.x_hi (see LaneGradConst).
+template <int NO, int L, bool GRAD, bool SUB = true, bool PRE0 = false, bool FASTDIV = false>
 __device__ __forceinline__ float reward_one(const ocd_scenario_desc &d, const float (&w)[OCD_MAX_FEATURES],
                                             float x, float y, float v, float sn, float cn,
                                             const BumpGeom (&bg)[NO > 0 ? NO : 1], const bool (&nc)[NO > 0 ? NO : 1],
@@ -732,7 +747,14 @@ __device__ __forceinline__ float reward_one(const ocd_scenario_desc &d, const fl
     const float e1 = exp_le1(m1 + addc), e2 = exp_le1(m2 + addc);
 #else
     const v2f U = {u1, u2};
-    const v2f M = div2_(splat2(-1.0f), U);
+    v2f M, Kk;
+    if constexpr (FASTDIV && GRAD) {
+        // both quotients of this pass by the denominators U at once, without the scaling / fix-up instructions: the
+        // caller has checked the guard (LaneGradConst::x_hi) for every live fence lane
+        recip_pair_guarded(U, M, Kk);
+    } else {
+        M = div2_(splat2(-1.0f), U);
+    }
     const v2f E = exp_le1_2(M + splat2(addc), pkc);
     const float m1 = M.x, m2 = M.y, e1 = E.x, e2 = E.y;
 #endif
@@ -765,7 +787,7 @@ __device__ __forceinline__ float reward_one(const ocd_scenario_desc &d, const fl
 #ifdef OCD_NO_PACKED
     const float k1 = (-m1) / u1, k2 = (-m2) / u2;
 #else
-    const v2f Kk = div2_(-M, U);
+    if constexpr (!(FASTDIV && GRAD)) Kk = div2_(-M, U);
     const float k1 = Kk.x, k2 = Kk.y;
 #endif
     if constexpr (!PRE0) {

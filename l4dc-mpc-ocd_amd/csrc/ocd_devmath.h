@@ -130,6 +130,33 @@ __device__ __forceinline__ v2f div2_(v2f n, v2f d)
     return out;
 }
 
+// m = -1/d and k = (-m)/d (= div2_(splat2(-1), d) and div2_(-m, d)) for denominators the CALLER has shown to lie in
+// [2^-32, 2^40]: there v_div_scale_f32 returns both operands of both divisions unchanged with VCC = 0 (numerators -1 and
+// 1/d: no exponent difference near +-96 / -126, nothing denormal), v_div_fmas_f32 is the plain fma and v_div_fixup_f32
+// passes the quotient through -- so the two divisions are the operations below, the SAME operations on the same values
+// as div2_'s, with the scaling / fix-up instructions (identities) left out and ONE reciprocal refinement serving both
+// (same denominator -> same v_rcp_f32, same two fma).  17 issue slots instead of 38.
+__device__ __forceinline__ void recip_pair_guarded(v2f d, v2f &m, v2f &k)
+{
+    v2f r, r1, e, q;
+    r.x = __builtin_amdgcn_rcpf(d.x);
+    r.y = __builtin_amdgcn_rcpf(d.y);
+    asm("s_nop 0\n"
+        "v_pk_fma_f32 %[e], %[d], %[r], 1.0 op_sel_hi:[1,1,0] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"     // 1 - d*r
+        "v_pk_fma_f32 %[r1], %[e], %[r], %[r]\n"                                                   // refined reciprocal
+        "v_pk_mul_f32 %[q], %[r1], -1.0 op_sel_hi:[1,0]\n"                                         // n*r1, n = -1
+        "v_pk_fma_f32 %[e], %[d], %[q], -1.0 op_sel_hi:[1,1,0] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"    // n - d*q
+        "v_pk_fma_f32 %[q], %[e], %[r1], %[q]\n"
+        "v_pk_fma_f32 %[e], %[d], %[q], -1.0 op_sel_hi:[1,1,0] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+        "v_pk_fma_f32 %[m], %[e], %[r1], %[q]\n"                                                   // (v_div_fmas_f32, VCC = 0)
+        "v_pk_mul_f32 %[q], %[m], %[r1] neg_lo:[1,0] neg_hi:[1,0]\n"                               // n*r1, n = -m
+        "v_pk_fma_f32 %[e], %[d], %[q], %[m] neg_lo:[1,0,1] neg_hi:[1,0,1]\n"                      // n - d*q
+        "v_pk_fma_f32 %[q], %[e], %[r1], %[q]\n"
+        "v_pk_fma_f32 %[e], %[d], %[q], %[m] neg_lo:[1,0,1] neg_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %[k], %[e], %[r1], %[q]\n"
+        : [e] "=&v"(e), [r1] "=&v"(r1), [q] "=&v"(q), [m] "=&v"(m), [k] "=&v"(k) : [d] "v"(d), [r] "v"(r));
+}
+
 // Constants of exp_le1_2, two per VGPR pair (a packed instruction picks the low or the high dword of a
 // source for both of its lanes through op_sel / op_sel_hi).  Built once per kernel and pinned in registers.
 struct PkConsts { v2f a, b, c, d, e; };

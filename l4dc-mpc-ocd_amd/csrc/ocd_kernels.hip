@@ -218,7 +218,7 @@ mpc_kernel(const KernelParams p)
         for (int k = 0; k < OCD_MAX_FEATURES; ++k) w[k] = (wp && k < D) ? wp[k] : 0.0f;
         tp_idx = p.sample_fixed;
     }
-    const LaneGradConst<L> lgc = lane_grad_const<L>(w);   // lane-feature gradient factors of this trajectory
+    const LaneGradConst<L> lgc = lane_grad_const<L>(w, d);   // lane-feature gradient factors of this trajectory
     float wd[OCD_MAX_FEATURES];               // designer weights (uniform)
 #pragma unroll
     for (int k = 0; k < OCD_MAX_FEATURES; ++k) wd[k] = d.designer_weights[k];
@@ -490,29 +490,34 @@ mpc_kernel(const KernelParams p)
                 }
                 const bool has_f = mf != 0ull, has_col = mc_any != 0ull;
                 const unsigned long long any_feat = mf | mc_any;
+                // LAT: a fence lane beyond the guard of the shortened reciprocals (LaneGradConst::x_hi) -> full divisions
+                unsigned long long beyond = 0ull;
+                if constexpr (LAT) beyond = __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(xn) < lgc.x_hi)) & mf;
                 OCD_STAMP(4);                              // choice of the evaluation
                 if constexpr (LAT && NO >= 2) {
                     // several scripted cars: the reference's scenarios of that kind (replanning, merging) put cars where
                     // their collision box overlaps the fence region, a pass with a multi-feature lane is COMMON (most
                     // passes of the slowest wavefronts): decided before the evaluation, one evaluation per pass
-                    if (__builtin_expect((multi_f | multi_c) != 0ull, 0)) {
+                    if (__builtin_expect((multi_f | multi_c | beyond) != 0ull, 0)) {
                         if (multi_c != 0ull) r = reward_every<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, pkc);
-                        else r = reward_fc<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, nc, q, pkc);
-                        OCD_STAMP(5); OCD_STAMP_COUNT(12); // every feature / fence + one car per lane
+                        else if (multi_f != 0ull) r = reward_fc<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, nc, q, pkc);
+                        else r = reward_one<NO, L, GRAD, false, phi0_in_chain>(d, w, xn, yn, vn, sn, cn, bg, nc, nf, true, true, q, pkc, lgc, feat_mask);
+                        OCD_STAMP(5); OCD_STAMP_COUNT(12); // every feature / fence + one car per lane / full divisions
                     } else {
-                        r = reward_one<NO, L, GRAD, false, phi0_in_chain>(d, w, xn, yn, vn, sn, cn, bg, nc, nf, true, true, q, pkc, lgc, feat_mask);
+                        r = reward_one<NO, L, GRAD, false, phi0_in_chain, GRAD>(d, w, xn, yn, vn, sn, cn, bg, nc, nf, true, true, q, pkc, lgc, feat_mask);
                         OCD_STAMP(6); OCD_STAMP_COUNT(13); // one feature per lane
                     }
                 } else if constexpr (LAT) {
                     // one scripted car (finite_horizon, local_opt: its collision box and the fence region do not overlap,
                     // a multi-feature lane is rare or impossible): one feature per lane, straight line; the rare pass is
                     // repaired afterwards, out of line -- the hot path carries no trace of it
-                    r = reward_one<NO, L, GRAD, false, phi0_in_chain>(d, w, xn, yn, vn, sn, cn, bg, nc, nf, true, true, q, pkc, lgc, feat_mask);
+                    r = reward_one<NO, L, GRAD, false, phi0_in_chain, GRAD>(d, w, xn, yn, vn, sn, cn, bg, nc, nf, true, true, q, pkc, lgc, feat_mask);
                     OCD_STAMP(6); OCD_STAMP_COUNT(13);     // one feature per lane
-                    if (__builtin_expect((multi_f | multi_c) != 0ull, 0)) {
+                    if (__builtin_expect((multi_f | multi_c | beyond) != 0ull, 0)) {
                         if (multi_c != 0ull) r = reward_every<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, pkc);
-                        else r = reward_fc<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, nc, q, pkc);
-                        OCD_STAMP(5); OCD_STAMP_COUNT(12); // every feature / fence + one car per lane
+                        else if (multi_f != 0ull) r = reward_fc<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, nc, q, pkc);
+                        else r = reward_one<NO, L, GRAD, false, phi0_in_chain>(d, w, xn, yn, vn, sn, cn, bg, nc, nf, true, true, q, pkc, lgc, feat_mask);
+                        OCD_STAMP(5); OCD_STAMP_COUNT(12); // every feature / fence + one car per lane / full divisions
                     }
                 } else {
                     // (the diagnostics knobs enter as two wave-uniform masks: two scalar tests decide the path)

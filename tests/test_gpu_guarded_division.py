@@ -1,0 +1,79 @@
+"""The straight-line builds take the reciprocals -1/u and (1/u)/u of a pass without the scaling / fix-up instructions of
+the IEEE division when every live fence lane is inside a guard (csrc/ocd_device.h: LaneGradConst::x_hi,
+csrc/ocd_devmath.h: recip_pair_guarded), and the full divisions otherwise.  Both sides of that guard, and the
+denominators closest to its assumptions (an ego a few units in the last place inside the fence region; a fence that starts
+at 0, where the guard is switched off), against the CPU oracle, bit for bit."""
+import numpy as np
+import pytest
+
+from l4dc_mpc_ocd_amd import abi, scenarios
+
+pytestmark = pytest.mark.gpu
+
+
+def same(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and bool(((a == b) | (np.isnan(a) & np.isnan(b))).all())
+
+
+def edge_positions(lo, width):
+    """x just outside / inside the fence region's two edges, by units in the last place, both signs; then far outside."""
+    lo, hi = np.float32(lo), np.float32(lo) + np.float32(width)
+    xs = []
+    for edge in (lo, hi):
+        x = edge
+        for _ in range(4):
+            x = np.nextafter(x, np.float32(-np.inf), dtype=np.float32)
+        for _ in range(24):
+            xs.append(x)
+            x = np.nextafter(x, np.float32(np.inf), dtype=np.float32)
+    xs = np.array(xs, dtype=np.float32)
+    far = np.array([0.5, 3.0, 1e3, 1e6, 1e9, 2.7e9, 2.8e9, 1e10, 1e15, 1e25, 3e38], dtype=np.float32)
+    return np.concatenate([xs, -xs, far, -far])
+
+
+CASES = [("local_opt", 10, {}), ("finite_horizon", 5, {}), ("finite_horizon", 6, {"extra_inits": True}),
+         ("replanning", 5, {}), ("replanning", 15, {}), ("merging", 25, {}), ("merging", 10, {})]
+
+
+def mapping_exists(H, kw, mode):
+    K = 6 if kw.get("extra_inits") else 3
+    return not ((mode == 2 and H > 16) or (mode == 3 and K * H > 64) or (mode == 4 and H < 10))
+
+
+COMBOS = [(n, H, kw, m, z) for n, H, kw in CASES for m in (0, 2, 3, 4) for z in (False, True) if mapping_exists(H, kw, m)]
+
+
+@pytest.mark.parametrize("name,H,kw,mode,fence_from_zero", COMBOS)
+def test_fence_edges_and_far_positions_bitwise(hip, oracle, name, H, kw, mode, fence_from_zero):
+    from l4dc_mpc_ocd_amd.engine import Engine
+    base = scenarios.SCENARIOS[name](horizon=H, **kw)
+    assert base.desc.n_ctrl_inits == (6 if kw.get("extra_inits") else 3)
+    d = abi.ScenarioDesc.from_buffer_copy(bytes(base.desc))
+    d.n_iter = 4
+    if fence_from_zero:
+        d.fence_lo = 0.0                                       # every |x| > 0 is a fence lane, denominators down to denormals
+    scn = scenarios.Scenario(base.name + "_edges", d, base.init_dist, None)
+    xs = edge_positions(d.fence_lo, d.fence_width)
+    if fence_from_zero:
+        xs = np.concatenate([xs, np.array([1e-45, 1e-40, 1e-38, 1e-30, 1e-20, -1e-45, -1e-38, 0.0], dtype=np.float32)])
+    B = xs.size
+    C = d.n_cars
+    ws = np.zeros((B, C, 4), dtype=np.float32)
+    ws[:, 0, 0] = xs
+    ws[:, 0, 1] = -0.9
+    ws[:, 0, 2] = 0.0                                          # at rest: the first pass evaluates the features AT x
+    ws[:, 0, 3] = np.pi / 2
+    for j in range(C - 1):
+        ws[:, j + 1] = np.array(d.other_init[j][:], dtype=np.float32)
+    w = scenarios.planner_weights_fp32(base.candidate_weights(1, seed=4)[0])
+    eng = Engine(scn, "cuda:0")
+    eng.set_option("scan_mode", mode)
+    if mode == 4:
+        eng.set_option("chunk_size", 5 if H % 5 == 0 else 2)
+    out = eng.plan_batch(ws, w, want_all=True)
+    assert eng.last_launch()["build_wavefronts_per_simd"] in (0, 1)
+    ref = oracle.plan_batch(d, ws, w, other_plans=scn.other_plans())
+    for k in ("all_losses", "all_plans", "plans", "best_loss"):
+        assert same(out[k], ref[k]), (name, H, mode, k)
+    assert np.array_equal(out["best_init"], ref["best_init"])
