@@ -215,6 +215,21 @@ mpc_chunk_kernel(const KernelParams p)
         for (int s = 0; s < S; ++s)
 #pragma unroll
             for (int j = 0; j < NOA; ++j) { wx1[s][j] = bg[s][j].wx * 1.001f; wy1[s][j] = bg[s][j].wy * 1.001f; }
+        // LAT: one scripted car: the refined reciprocals of its half-widths in this control step (reward_one's FASTDIV form divides by
+        // them in every pass) and the lanes whose widths are outside its guard
+        BumpRecip br[S][NOA];
+        unsigned long long widths_beyond = 0ull;
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int j = 0; j < NOA; ++j) {
+                br[s][j] = BumpRecip{0.0f, 0.0f};
+                if constexpr (LAT && lane_feats && NO == 1) {
+                    br[s][j].rx = refined_recip(bg[s][j].wx);
+                    br[s][j].ry = refined_recip(bg[s][j].wy);
+                    widths_beyond |= __builtin_amdgcn_ballot_w64(!bump_widths_guarded(bg[s][j]));
+                }
+            }
 
         // ---- control initialisation of this segment (naive_planner.py:107-116) ----
         float s0, c0;
@@ -347,7 +362,7 @@ mpc_chunk_kernel(const KernelParams p)
                     const bool nf = needs_fence(d, xn);
                     const unsigned long long lm = (s >= SL) ? real_mask : live_mask;
                     const unsigned long long mf = __builtin_amdgcn_ballot_w64(nf) & lm;
-                    unsigned long long mc_any = 0ull, multi_f = 0ull, multi_c = 0ull;
+                    unsigned long long mc_any = 0ull, multi_f = 0ull, multi_c = 0ull, tiny_n = 0ull;
 #pragma unroll
                     for (int j = 0; j < NO; ++j) {
                         const float dx = xn - bg[s][j].cx, dy = yn - bg[s][j].cy;
@@ -357,9 +372,13 @@ mpc_chunk_kernel(const KernelParams p)
                         multi_f |= (mj & mf);
                         multi_c |= (mj & mc_any);
                         mc_any |= mj;
+                        if constexpr (NO == 1)             // a zero / tiny numerator of the shortened (x - cx) / wx
+                            tiny_n |= __builtin_amdgcn_ballot_w64(__builtin_fabsf(dx) < 7.888609052210118e-31f) |
+                                  __builtin_amdgcn_ballot_w64(__builtin_fabsf(dy) < 7.888609052210118e-31f);
                     }
-                    // a fence lane beyond the guard of the shortened reciprocals (LaneGradConst::x_hi): the full divisions
-                    const unsigned long long beyond = __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(xn) < lgc.x_hi)) & mf;
+                    // beyond the guards of the shortened divisions (LaneGradConst::x_hi, quot2_by_recip): the full ones
+                    const unsigned long long beyond = (__builtin_amdgcn_ballot_w64(!(__builtin_fabsf(xn) < lgc.x_hi)) & mf) |
+                                                      ((tiny_n | widths_beyond) & lm);
                     OCD_STAMP(4);                          // choice of the evaluation
                     if (__builtin_expect((multi_f | multi_c | beyond) != 0ull, 0)) {
                         if (multi_c != 0ull)
@@ -367,11 +386,11 @@ mpc_chunk_kernel(const KernelParams p)
                         else if (multi_f != 0ull)
                             rw[s] = reward_fc<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], nc, q[s], pkc);
                         else
-                            rw[s] = reward_one<NO, L, GRAD, false>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], nc, nf, true, true,
+                            rw[s] = reward_one<NO, L, GRAD, false>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], br[s], nc, nf, true, true,
                                                                    q[s], pkc, lgc, lm);
                         OCD_STAMP(5); OCD_STAMP_COUNT(12);
                     } else {
-                        rw[s] = reward_one<NO, L, GRAD, false, false, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], nc, nf, true,
+                        rw[s] = reward_one<NO, L, GRAD, false, false, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], br[s], nc, nf, true,
                                                                             true, q[s], pkc, lgc, lm);
                         OCD_STAMP(6); OCD_STAMP_COUNT(13);
                     }
@@ -411,7 +430,7 @@ mpc_chunk_kernel(const KernelParams p)
                             rw[s] = reward_fc<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], nc, q[s], pkc);
                             OCD_STAMP(5); OCD_STAMP_COUNT(12);
                         } else if (has_f || has_col) {
-                            rw[s] = reward_one<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], nc, nf, has_col, has_f, q[s], pkc, lgc, lm);
+                            rw[s] = reward_one<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], br[s], nc, nf, has_col, has_f, q[s], pkc, lgc, lm);
                             OCD_STAMP(6); OCD_STAMP_COUNT(13);
                             if (has_col) OCD_STAMP_COUNT(11);
                             if (has_f) OCD_STAMP_COUNT(15);

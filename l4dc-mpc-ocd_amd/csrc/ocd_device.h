@@ -146,6 +146,17 @@ __device__ __forceinline__ BumpGeom bump_geom(float ox, float oy, float hx, floa
     return g;
 }
 
+// refined reciprocals of a BumpGeom's half-widths (ocd_devmath.h: refined_recip), once per control step: reward_one's
+// FASTDIV form divides by them
+struct BumpRecip { float rx, ry; };
+
+// the half-widths a FASTDIV pass may divide by through quot2_by_recip: [2^-20, 2^20] (false for NaN)
+__device__ __forceinline__ bool bump_widths_guarded(const BumpGeom &g)
+{
+    const float lo = 9.5367431640625e-7f, hi = 1048576.0f;
+    return g.wx >= lo && g.wx <= hi && g.wy >= lo && g.wy <= hi;
+}
+
 struct Q4 { float qx, qy, qv, qth; };
 
 // The kernels' template parameter L: > 0 = lane-feature reward with L lanes, 0 = target-speed test reward,
@@ -675,11 +686,16 @@ __device__ __forceinline__ LaneGradConst<L> lane_grad_const(const float (&w)[OCD
 // in nearly every pass: the skips only help where several wavefronts share a SIMD.
 // PRE0 (GRAD only): the caller has filled q.qv / q.qth with the target-speed feature's adjoint already (the
 // V_ROW build computes it in the hazard slots of the position recurrence, ocd_chains.h).
-// FASTDIV (GRAD only): precondition -- every live fence lane has |x| < lgc.x_hi (see LaneGradConst).
+// FASTDIV (GRAD only): preconditions, tested by the caller for every live lane -- a fence lane has |x| < lgc.x_hi (see
+// LaneGradConst); with ONE scripted car also: its half-widths are bump_widths_guarded, br[0] their refined reciprocals,
+// and |x - cx|, |y - cy| >= 2^-100 (quot2_by_recip).  (With two cars the per-lane choice of the reciprocals and the four
+// extra tests cost more than the shorter division returns -- most of their passes take reward_fc / reward_every anyway:
+// measured +1.5...+2.2 % on the per-GPU shares of configs 4 / 5.)
 template <int NO, int L, bool GRAD, bool SUB = true, bool PRE0 = false, bool FASTDIV = false>
 __device__ __forceinline__ float reward_one(const ocd_scenario_desc &d, const float (&w)[OCD_MAX_FEATURES],
                                             float x, float y, float v, float sn, float cn,
-                                            const BumpGeom (&bg)[NO > 0 ? NO : 1], const bool (&nc)[NO > 0 ? NO : 1],
+                                            const BumpGeom (&bg)[NO > 0 ? NO : 1], const BumpRecip (&br)[NO > 0 ? NO : 1],
+                                            const bool (&nc)[NO > 0 ? NO : 1],
                                             const bool is_f, const bool has_col_, const bool has_f_, Q4 &q,
                                             const PkConsts &pkc, const LaneGradConst<L> &lgc,
                                             const unsigned long long live_mask)
@@ -708,6 +724,7 @@ __device__ __forceinline__ float reward_one(const ocd_scenario_desc &d, const fl
 
     // the one scripted car this lane may be colliding with
     BumpGeom g = bg[0];
+    BumpRecip gr = br[0];
 #pragma unroll
     for (int j = 1; j < NO; ++j) {
         g.cx = nc[j] ? bg[j].cx : g.cx; g.wx = nc[j] ? bg[j].wx : g.wx;
@@ -730,7 +747,9 @@ __device__ __forceinline__ float reward_one(const ocd_scenario_desc &d, const fl
         const float znx = (x - g.cx) / g.wx;
         const float zny = (y - g.cy) / g.wy;
 #else
-        const v2f ZN = div2_(v2f{x - g.cx, y - g.cy}, v2f{g.wx, g.wy});
+        v2f ZN;
+        if constexpr (FASTDIV && GRAD && NO == 1) ZN = quot2_by_recip(v2f{x - g.cx, y - g.cy}, v2f{g.wx, g.wy}, v2f{gr.rx, gr.ry});
+        else ZN = div2_(v2f{x - g.cx, y - g.cy}, v2f{g.wx, g.wy});
         const float znx = ZN.x, zny = ZN.y;
 #endif
         condx = (znx * znx) < 1.0f;

@@ -157,6 +157,32 @@ __device__ __forceinline__ void recip_pair_guarded(v2f d, v2f &m, v2f &k)
         : [e] "=&v"(e), [r1] "=&v"(r1), [q] "=&v"(q), [m] "=&v"(m), [k] "=&v"(k) : [d] "v"(d), [r] "v"(r));
 }
 
+// The refined reciprocal div2_ computes for a denominator it does not scale (v_rcp_f32 and one Newton step): for
+// denominators that stay the same over many divisions (the bump half-widths of a control step), computed once.
+__device__ __forceinline__ float refined_recip(float d)
+{
+    const float r = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+
+// n / d for two quotients, d in [2^-20, 2^20] with r1 = refined_recip(d), |n| in [2^-100, 2^76): there v_div_scale_f32
+// changes neither operand, v_div_fmas_f32 is the plain fma and v_div_fixup_f32 passes the quotient through, so these five
+// operations are div2_'s own (same operations, same values).  Beyond that range on the large side (or for a NaN / an
+// infinite n) the result is some value of magnitude >= 2^56, an infinity or a NaN -- enough for the caller here, who
+// only asks whether the square is below 1; zero and tiny numerators are the caller's to exclude.
+__device__ __forceinline__ v2f quot2_by_recip(v2f n, v2f d, v2f r1)
+{
+    v2f e, q, out;
+    asm("v_pk_mul_f32 %[q], %[n], %[r1]\n"
+        "v_pk_fma_f32 %[e], %[d], %[q], %[n] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+        "v_pk_fma_f32 %[q], %[e], %[r1], %[q]\n"
+        "v_pk_fma_f32 %[e], %[d], %[q], %[n] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+        "v_pk_fma_f32 %[out], %[e], %[r1], %[q]\n"
+        : [e] "=&v"(e), [q] "=&v"(q), [out] "=&v"(out) : [n] "v"(n), [d] "v"(d), [r1] "v"(r1));
+    return out;
+}
+
 // Constants of exp_le1_2, two per VGPR pair (a packed instruction picks the low or the high dword of a
 // source for both of its lanes through op_sel / op_sel_hi).  Built once per kernel and pinned in registers.
 struct PkConsts { v2f a, b, c, d, e; };

@@ -307,6 +307,19 @@ mpc_kernel(const KernelParams p)
         float wx1[NOA], wy1[NOA];                // 1.001 * bump half-widths (needs_collision1)
 #pragma unroll
         for (int j = 0; j < NOA; ++j) { wx1[j] = bg[j].wx * 1.001f; wy1[j] = bg[j].wy * 1.001f; }
+        // LAT: one scripted car: the refined reciprocals of its half-widths in this control step (reward_one's FASTDIV form divides by
+        // them in every pass) and the lanes whose widths are outside its guard
+        BumpRecip br[NOA];
+        unsigned long long widths_beyond = 0ull;
+#pragma unroll
+        for (int j = 0; j < NOA; ++j) {
+            br[j] = BumpRecip{0.0f, 0.0f};
+            if constexpr (LAT && lane_feats && NO == 1) {
+                br[j].rx = refined_recip(bg[j].wx);
+                br[j].ry = refined_recip(bg[j].wy);
+                widths_beyond |= __builtin_amdgcn_ballot_w64(!bump_widths_guarded(bg[j]));
+            }
+        }
 
         // ---- this lane's control initialisation (naive_planner.py:107-116) ----
         float s0, c0;
@@ -478,6 +491,7 @@ mpc_kernel(const KernelParams p)
                 const bool nf = needs_fence(d, xn);
                 // multi_f: some lane has the fence AND a car active; multi_c: some lane is inside two cars' boxes
                 unsigned long long mf = __builtin_amdgcn_ballot_w64(nf) & feat_mask, mc_any = 0ull, multi_f = 0ull, multi_c = 0ull;
+                unsigned long long tiny_n = 0ull;
 #pragma unroll
                 for (int j = 0; j < NO; ++j) {
                     const float dx = xn - bg[j].cx, dy = yn - bg[j].cy;
@@ -487,12 +501,16 @@ mpc_kernel(const KernelParams p)
                     multi_f |= (mj & mf);
                     multi_c |= (mj & mc_any);
                     mc_any |= mj;
+                    if constexpr (LAT && NO == 1)          // a zero / tiny numerator of the shortened (x - cx) / wx
+                        tiny_n |= __builtin_amdgcn_ballot_w64(__builtin_fabsf(dx) < 7.888609052210118e-31f) |
+                                  __builtin_amdgcn_ballot_w64(__builtin_fabsf(dy) < 7.888609052210118e-31f);
                 }
                 const bool has_f = mf != 0ull, has_col = mc_any != 0ull;
                 const unsigned long long any_feat = mf | mc_any;
                 // LAT: a fence lane beyond the guard of the shortened reciprocals (LaneGradConst::x_hi) -> full divisions
                 unsigned long long beyond = 0ull;
-                if constexpr (LAT) beyond = __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(xn) < lgc.x_hi)) & mf;
+                if constexpr (LAT)
+                    beyond = (__builtin_amdgcn_ballot_w64(!(__builtin_fabsf(xn) < lgc.x_hi)) & mf) | ((tiny_n | widths_beyond) & feat_mask);
                 OCD_STAMP(4);                              // choice of the evaluation
                 if constexpr (LAT && NO >= 2) {
                     // several scripted cars: the reference's scenarios of that kind (replanning, merging) put cars where
@@ -501,22 +519,22 @@ mpc_kernel(const KernelParams p)
                     if (__builtin_expect((multi_f | multi_c | beyond) != 0ull, 0)) {
                         if (multi_c != 0ull) r = reward_every<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, pkc);
                         else if (multi_f != 0ull) r = reward_fc<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, nc, q, pkc);
-                        else r = reward_one<NO, L, GRAD, false, phi0_in_chain>(d, w, xn, yn, vn, sn, cn, bg, nc, nf, true, true, q, pkc, lgc, feat_mask);
+                        else r = reward_one<NO, L, GRAD, false, phi0_in_chain>(d, w, xn, yn, vn, sn, cn, bg, br, nc, nf, true, true, q, pkc, lgc, feat_mask);
                         OCD_STAMP(5); OCD_STAMP_COUNT(12); // every feature / fence + one car per lane / full divisions
                     } else {
-                        r = reward_one<NO, L, GRAD, false, phi0_in_chain, GRAD>(d, w, xn, yn, vn, sn, cn, bg, nc, nf, true, true, q, pkc, lgc, feat_mask);
+                        r = reward_one<NO, L, GRAD, false, phi0_in_chain, GRAD>(d, w, xn, yn, vn, sn, cn, bg, br, nc, nf, true, true, q, pkc, lgc, feat_mask);
                         OCD_STAMP(6); OCD_STAMP_COUNT(13); // one feature per lane
                     }
                 } else if constexpr (LAT) {
                     // one scripted car (finite_horizon, local_opt: its collision box and the fence region do not overlap,
                     // a multi-feature lane is rare or impossible): one feature per lane, straight line; the rare pass is
                     // repaired afterwards, out of line -- the hot path carries no trace of it
-                    r = reward_one<NO, L, GRAD, false, phi0_in_chain, GRAD>(d, w, xn, yn, vn, sn, cn, bg, nc, nf, true, true, q, pkc, lgc, feat_mask);
+                    r = reward_one<NO, L, GRAD, false, phi0_in_chain, GRAD>(d, w, xn, yn, vn, sn, cn, bg, br, nc, nf, true, true, q, pkc, lgc, feat_mask);
                     OCD_STAMP(6); OCD_STAMP_COUNT(13);     // one feature per lane
                     if (__builtin_expect((multi_f | multi_c | beyond) != 0ull, 0)) {
                         if (multi_c != 0ull) r = reward_every<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, pkc);
                         else if (multi_f != 0ull) r = reward_fc<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, nc, q, pkc);
-                        else r = reward_one<NO, L, GRAD, false, phi0_in_chain>(d, w, xn, yn, vn, sn, cn, bg, nc, nf, true, true, q, pkc, lgc, feat_mask);
+                        else r = reward_one<NO, L, GRAD, false, phi0_in_chain>(d, w, xn, yn, vn, sn, cn, bg, br, nc, nf, true, true, q, pkc, lgc, feat_mask);
                         OCD_STAMP(5); OCD_STAMP_COUNT(12); // every feature / fence + one car per lane / full divisions
                     }
                 } else {
@@ -530,7 +548,7 @@ mpc_kernel(const KernelParams p)
                             r = reward_fc<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, nc, q, pkc);
                             OCD_STAMP(5); OCD_STAMP_COUNT(12);     // fence + one car per lane
                         } else {
-                            r = reward_one<NO, L, GRAD, true>(d, w, xn, yn, vn, sn, cn, bg, nc, nf, has_col, has_f, q, pkc, lgc, feat_mask);
+                            r = reward_one<NO, L, GRAD, true>(d, w, xn, yn, vn, sn, cn, bg, br, nc, nf, has_col, has_f, q, pkc, lgc, feat_mask);
                             OCD_STAMP(6); OCD_STAMP_COUNT(13);     // one feature per lane
                             if (has_col) OCD_STAMP_COUNT(11);
                             if (has_f) OCD_STAMP_COUNT(15);

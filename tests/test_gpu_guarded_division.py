@@ -77,3 +77,38 @@ def test_fence_edges_and_far_positions_bitwise(hip, oracle, name, H, kw, mode, f
     for k in ("all_losses", "all_plans", "plans", "best_loss"):
         assert same(out[k], ref[k]), (name, H, mode, k)
     assert np.array_equal(out["best_init"], ref["best_init"])
+
+
+TINY = np.array([0.0, 1e-45, 1e-40, 1e-38, 1e-33, 5e-31, 7.8e-31, 8e-31, 1e-30, 1e-25, 1e-12, 1e-4], dtype=np.float32)
+
+
+@pytest.mark.parametrize("name,H,mode", [("local_opt", 10, 0), ("local_opt", 10, 2), ("local_opt", 10, 3), ("local_opt", 10, 4),
+                                          ("replanning", 5, 0), ("replanning", 5, 3), ("merging", 25, 4), ("merging", 10, 3)])
+def test_zero_and_tiny_bump_numerators_bitwise(hip, oracle, name, H, mode):
+    """(x - cx) / wx with the half-width's precomputed reciprocal needs |x - cx| >= 2^-100 (csrc/ocd_devmath.h:
+    quot2_by_recip): an ego exactly on a resting scripted car's centre, and denormal / tiny offsets from it on both
+    sides of that bound, in x and in y."""
+    from l4dc_mpc_ocd_amd.engine import Engine
+    base = scenarios.SCENARIOS[name](horizon=H)
+    d = abi.ScenarioDesc.from_buffer_copy(bytes(base.desc))
+    d.n_iter = 4
+    scn = scenarios.Scenario(base.name + "_tiny", d, base.init_dist, None)
+    offs = np.concatenate([TINY, -TINY])
+    dxs, dys = np.meshgrid(offs, offs[::3])
+    dxs, dys = dxs.ravel(), dys.ravel()
+    B, C = dxs.size, d.n_cars
+    ws = np.zeros((B, C, 4), dtype=np.float32)
+    ws[:, 0, 0], ws[:, 0, 1], ws[:, 0, 3] = dxs, dys, np.pi / 2          # the ego at rest at (dx, dy)
+    ws[:, 1] = np.array([0.0, 0.0, 0.0, np.pi / 2], dtype=np.float32)     # a scripted car at rest at the origin
+    for j in range(2, C):
+        ws[:, j] = np.array(d.other_init[j - 1][:], dtype=np.float32)
+    w = scenarios.planner_weights_fp32(base.candidate_weights(1, seed=4)[0])
+    eng = Engine(scn, "cuda:0")
+    eng.set_option("scan_mode", mode)
+    if mode == 4:
+        eng.set_option("chunk_size", 5)
+    out = eng.plan_batch(ws, w, want_all=True)
+    ref = oracle.plan_batch(d, ws, w, other_plans=scn.other_plans())
+    for k in ("all_losses", "all_plans", "plans", "best_loss"):
+        assert same(out[k], ref[k]), (name, H, mode, k)
+    assert np.array_equal(out["best_init"], ref["best_init"])
