@@ -215,7 +215,7 @@ mpc_chunk_kernel(const KernelParams p)
         for (int s = 0; s < S; ++s)
 #pragma unroll
             for (int j = 0; j < NOA; ++j) { wx1[s][j] = bg[s][j].wx * 1.001f; wy1[s][j] = bg[s][j].wy * 1.001f; }
-        // LAT: one scripted car: the refined reciprocals of its half-widths in this control step (reward_one's FASTDIV form divides by
+        // one scripted car: the refined reciprocals of its half-widths in this control step (reward_one's FASTDIV form divides by
         // them in every pass) and the lanes whose widths are outside its guard
         BumpRecip br[S][NOA];
         unsigned long long widths_beyond = 0ull;
@@ -224,7 +224,7 @@ mpc_chunk_kernel(const KernelParams p)
 #pragma unroll
             for (int j = 0; j < NOA; ++j) {
                 br[s][j] = BumpRecip{0.0f, 0.0f};
-                if constexpr (LAT && lane_feats && NO == 1) {
+                if constexpr (lane_feats && NO == 1) {
                     br[s][j].rx = refined_recip(bg[s][j].wx);
                     br[s][j].ry = refined_recip(bg[s][j].wy);
                     widths_beyond |= __builtin_amdgcn_ballot_w64(!bump_widths_guarded(bg[s][j]));
@@ -430,7 +430,18 @@ mpc_chunk_kernel(const KernelParams p)
                             rw[s] = reward_fc<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], nc, q[s], pkc);
                             OCD_STAMP(5); OCD_STAMP_COUNT(12);
                         } else if (has_f || has_col) {
-                            rw[s] = reward_one<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], br[s], nc, nf, has_col, has_f, q[s], pkc, lgc, lm);
+                            // the shortened reciprocals (ocd_devmath.h: recip_pair_guarded) unless a fence lane is beyond
+                            // their guard (LaneGradConst::x_hi); they need fewer registers than the full divisions
+                            // (one scripted car: also (x - cx) / wx by the reciprocals of this control step, quot2_by_recip)
+                            constexpr bool ZN1 = GRAD && NO == 1;
+                            unsigned long long tiny_n = 0ull;
+                            if constexpr (ZN1)
+                                tiny_n = (__ballot(__builtin_fabsf(xn - bg[s][0].cx) < 7.888609052210118e-31f) |
+                                          __ballot(__builtin_fabsf(yn - bg[s][0].cy) < 7.888609052210118e-31f) | widths_beyond) & lm;
+                            if (!GRAD || ((__ballot(!(__builtin_fabsf(xn) < lgc.x_hi)) & mf) | tiny_n) != 0ull)
+                                rw[s] = reward_one<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], br[s], nc, nf, has_col, has_f, q[s], pkc, lgc, lm);
+                            else
+                                rw[s] = reward_one<NO, L, GRAD, true, false, GRAD, ZN1>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], br[s], nc, nf, has_col, has_f, q[s], pkc, lgc, lm);
                             OCD_STAMP(6); OCD_STAMP_COUNT(13);
                             if (has_col) OCD_STAMP_COUNT(11);
                             if (has_f) OCD_STAMP_COUNT(15);

@@ -691,7 +691,7 @@ __device__ __forceinline__ LaneGradConst<L> lane_grad_const(const float (&w)[OCD
 // and |x - cx|, |y - cy| >= 2^-100 (quot2_by_recip).  (With two cars the per-lane choice of the reciprocals and the four
 // extra tests cost more than the shorter division returns -- most of their passes take reward_fc / reward_every anyway:
 // measured +1.5...+2.2 % on the per-GPU shares of configs 4 / 5.)
-template <int NO, int L, bool GRAD, bool SUB = true, bool PRE0 = false, bool FASTDIV = false>
+template <int NO, int L, bool GRAD, bool SUB = true, bool PRE0 = false, bool FASTDIV = false, bool FASTZN = FASTDIV && NO == 1>
 __device__ __forceinline__ float reward_one(const ocd_scenario_desc &d, const float (&w)[OCD_MAX_FEATURES],
                                             float x, float y, float v, float sn, float cn,
                                             const BumpGeom (&bg)[NO > 0 ? NO : 1], const BumpRecip (&br)[NO > 0 ? NO : 1],
@@ -702,6 +702,7 @@ __device__ __forceinline__ float reward_one(const ocd_scenario_desc &d, const fl
 {
     static_assert(L > 0 && NO > 0, "lane-feature reward only");
     static_assert(!PRE0 || GRAD, "PRE0 is a gradient-pass option");
+    static_assert(!FASTZN || (FASTDIV && NO == 1), "the reciprocal form of (x - cx) / wx: one scripted car, with FASTDIV");
     const bool has_col = SUB ? has_col_ : true, has_f = SUB ? has_f_ : true;
     const float tgt = d.target_speed;
     const float bound = 4.0f * (tgt * tgt);
@@ -748,7 +749,7 @@ __device__ __forceinline__ float reward_one(const ocd_scenario_desc &d, const fl
         const float zny = (y - g.cy) / g.wy;
 #else
         v2f ZN;
-        if constexpr (FASTDIV && GRAD && NO == 1) ZN = quot2_by_recip(v2f{x - g.cx, y - g.cy}, v2f{g.wx, g.wy}, v2f{gr.rx, gr.ry});
+        if constexpr (FASTZN && GRAD) ZN = quot2_by_recip(v2f{x - g.cx, y - g.cy}, v2f{g.wx, g.wy}, v2f{gr.rx, gr.ry});
         else ZN = div2_(v2f{x - g.cx, y - g.cy}, v2f{g.wx, g.wy});
         const float znx = ZN.x, zny = ZN.y;
 #endif

@@ -307,14 +307,14 @@ mpc_kernel(const KernelParams p)
         float wx1[NOA], wy1[NOA];                // 1.001 * bump half-widths (needs_collision1)
 #pragma unroll
         for (int j = 0; j < NOA; ++j) { wx1[j] = bg[j].wx * 1.001f; wy1[j] = bg[j].wy * 1.001f; }
-        // LAT: one scripted car: the refined reciprocals of its half-widths in this control step (reward_one's FASTDIV form divides by
+        // one scripted car: the refined reciprocals of its half-widths in this control step (reward_one's FASTDIV form divides by
         // them in every pass) and the lanes whose widths are outside its guard
         BumpRecip br[NOA];
         unsigned long long widths_beyond = 0ull;
 #pragma unroll
         for (int j = 0; j < NOA; ++j) {
             br[j] = BumpRecip{0.0f, 0.0f};
-            if constexpr (LAT && lane_feats && NO == 1) {
+            if constexpr (lane_feats && NO == 1) {
                 br[j].rx = refined_recip(bg[j].wx);
                 br[j].ry = refined_recip(bg[j].wy);
                 widths_beyond |= __builtin_amdgcn_ballot_w64(!bump_widths_guarded(bg[j]));
@@ -548,7 +548,18 @@ mpc_kernel(const KernelParams p)
                             r = reward_fc<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, nc, q, pkc);
                             OCD_STAMP(5); OCD_STAMP_COUNT(12);     // fence + one car per lane
                         } else {
-                            r = reward_one<NO, L, GRAD, true>(d, w, xn, yn, vn, sn, cn, bg, br, nc, nf, has_col, has_f, q, pkc, lgc, feat_mask);
+                            // the shortened reciprocals (ocd_devmath.h: recip_pair_guarded) unless a fence lane is beyond
+                            // their guard (LaneGradConst::x_hi)
+                            // (one scripted car: also (x - cx) / wx by the reciprocals of this control step, quot2_by_recip)
+                            constexpr bool ZN1 = GRAD && NO == 1;
+                            unsigned long long tiny_n = 0ull;
+                            if constexpr (ZN1)
+                                tiny_n = (__ballot(__builtin_fabsf(xn - bg[0].cx) < 7.888609052210118e-31f) |
+                                          __ballot(__builtin_fabsf(yn - bg[0].cy) < 7.888609052210118e-31f) | widths_beyond) & feat_mask;
+                            if (!GRAD || ((__ballot(!(__builtin_fabsf(xn) < lgc.x_hi)) & mf) | tiny_n) != 0ull)
+                                r = reward_one<NO, L, GRAD, true>(d, w, xn, yn, vn, sn, cn, bg, br, nc, nf, has_col, has_f, q, pkc, lgc, feat_mask);
+                            else
+                                r = reward_one<NO, L, GRAD, true, false, GRAD, ZN1>(d, w, xn, yn, vn, sn, cn, bg, br, nc, nf, has_col, has_f, q, pkc, lgc, feat_mask);
                             OCD_STAMP(6); OCD_STAMP_COUNT(13);     // one feature per lane
                             if (has_col) OCD_STAMP_COUNT(11);
                             if (has_f) OCD_STAMP_COUNT(15);

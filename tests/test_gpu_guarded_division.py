@@ -41,11 +41,15 @@ def mapping_exists(H, kw, mode):
     return not ((mode == 2 and H > 16) or (mode == 3 and K * H > 64) or (mode == 4 and H < 10))
 
 
-COMBOS = [(n, H, kw, m, z) for n, H, kw in CASES for m in (0, 2, 3, 4) for z in (False, True) if mapping_exists(H, kw, m)]
+COMBOS = [(n, H, kw, m, z, "latency") for n, H, kw in CASES for m in (0, 2, 3, 4) for z in (False, True) if mapping_exists(H, kw, m)]
+# the throughput builds take the shortened divisions too: the same positions with the latency builds switched off, and
+# tiled into a batch large enough for the three-wavefronts-per-SIMD builds (which the launcher then picks by itself)
+COMBOS += [(n, H, kw, m, z, "throughput") for n, H, kw in CASES for m in (0, 3, 4) for z in (False, True) if mapping_exists(H, kw, m)]
+COMBOS += [(n, H, {}, 0, z, "three_per_simd") for n, H in (("local_opt", 10), ("replanning", 15), ("merging", 25)) for z in (False, True)]
 
 
-@pytest.mark.parametrize("name,H,kw,mode,fence_from_zero", COMBOS)
-def test_fence_edges_and_far_positions_bitwise(hip, oracle, name, H, kw, mode, fence_from_zero):
+@pytest.mark.parametrize("name,H,kw,mode,fence_from_zero,build", COMBOS)
+def test_fence_edges_and_far_positions_bitwise(hip, oracle, name, H, kw, mode, fence_from_zero, build):
     from l4dc_mpc_ocd_amd.engine import Engine
     base = scenarios.SCENARIOS[name](horizon=H, **kw)
     assert base.desc.n_ctrl_inits == (6 if kw.get("extra_inits") else 3)
@@ -57,11 +61,13 @@ def test_fence_edges_and_far_positions_bitwise(hip, oracle, name, H, kw, mode, f
     xs = edge_positions(d.fence_lo, d.fence_width)
     if fence_from_zero:
         xs = np.concatenate([xs, np.array([1e-45, 1e-40, 1e-38, 1e-30, 1e-20, -1e-45, -1e-38, 0.0], dtype=np.float32)])
+    if build == "three_per_simd":
+        xs = np.tile(xs, 34 * 1024 // xs.size + 1)
     B = xs.size
     C = d.n_cars
     ws = np.zeros((B, C, 4), dtype=np.float32)
     ws[:, 0, 0] = xs
-    ws[:, 0, 1] = -0.9
+    ws[:, 0, 1] = -0.9 + (np.arange(B) % 7) * np.float32(0.01)
     ws[:, 0, 2] = 0.0                                          # at rest: the first pass evaluates the features AT x
     ws[:, 0, 3] = np.pi / 2
     for j in range(C - 1):
@@ -69,11 +75,13 @@ def test_fence_edges_and_far_positions_bitwise(hip, oracle, name, H, kw, mode, f
     w = scenarios.planner_weights_fp32(base.candidate_weights(1, seed=4)[0])
     eng = Engine(scn, "cuda:0")
     eng.set_option("scan_mode", mode)
+    eng.set_option("no_latency_build", int(build == "throughput"))
     if mode == 4:
         eng.set_option("chunk_size", 5 if H % 5 == 0 else 2)
     out = eng.plan_batch(ws, w, want_all=True)
-    assert eng.last_launch()["build_wavefronts_per_simd"] in (0, 1)
-    ref = oracle.plan_batch(d, ws, w, other_plans=scn.other_plans())
+    built = eng.last_launch()["build_wavefronts_per_simd"]
+    assert built == {"latency": built, "throughput": 0, "three_per_simd": 3}[build], eng.last_launch()
+    ref = oracle.plan_batch(d, ws, w, other_plans=scn.other_plans(), n_threads=8)
     for k in ("all_losses", "all_plans", "plans", "best_loss"):
         assert same(out[k], ref[k]), (name, H, mode, k)
     assert np.array_equal(out["best_init"], ref["best_init"])
@@ -84,7 +92,8 @@ TINY = np.array([0.0, 1e-45, 1e-40, 1e-38, 1e-33, 5e-31, 7.8e-31, 8e-31, 1e-30, 
 
 @pytest.mark.parametrize("name,H,mode", [("local_opt", 10, 0), ("local_opt", 10, 2), ("local_opt", 10, 3), ("local_opt", 10, 4),
                                           ("replanning", 5, 0), ("replanning", 5, 3), ("merging", 25, 4), ("merging", 10, 3)])
-def test_zero_and_tiny_bump_numerators_bitwise(hip, oracle, name, H, mode):
+@pytest.mark.parametrize("no_lat", [0, 1])
+def test_zero_and_tiny_bump_numerators_bitwise(hip, oracle, name, H, mode, no_lat):
     """(x - cx) / wx with the half-width's precomputed reciprocal needs |x - cx| >= 2^-100 (csrc/ocd_devmath.h:
     quot2_by_recip): an ego exactly on a resting scripted car's centre, and denormal / tiny offsets from it on both
     sides of that bound, in x and in y."""
@@ -105,6 +114,7 @@ def test_zero_and_tiny_bump_numerators_bitwise(hip, oracle, name, H, mode):
     w = scenarios.planner_weights_fp32(base.candidate_weights(1, seed=4)[0])
     eng = Engine(scn, "cuda:0")
     eng.set_option("scan_mode", mode)
+    eng.set_option("no_latency_build", no_lat)
     if mode == 4:
         eng.set_option("chunk_size", 5)
     out = eng.plan_batch(ws, w, want_all=True)
