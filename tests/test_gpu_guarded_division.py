@@ -27,6 +27,9 @@ def edge_positions(lo, width):
         for _ in range(24):
             xs.append(x)
             x = np.nextafter(x, np.float32(np.inf), dtype=np.float32)
+    # exp(-1/u) between FLT_MIN and 2^-100 (u = 100 * (x - lo) in [0.0114, 0.0145]): the tiny but non-zero numerators
+    # the shortened S = F1 / den and g / den leave to the full divisions
+    xs += list(lo + np.linspace(1.0e-4, 1.6e-4, 31, dtype=np.float32))
     xs = np.array(xs, dtype=np.float32)
     far = np.array([0.5, 3.0, 1e3, 1e6, 1e9, 2.7e9, 2.8e9, 1e10, 1e15, 1e25, 3e38], dtype=np.float32)
     return np.concatenate([xs, -xs, far, -far])
@@ -105,6 +108,10 @@ def test_zero_and_tiny_bump_numerators_bitwise(hip, oracle, name, H, mode, no_la
     offs = np.concatenate([TINY, -TINY])
     dxs, dys = np.meshgrid(offs, offs[::3])
     dxs, dys = dxs.ravel(), dys.ravel()
+    # near the corners of the collision box both bump exponentials are tiny: gradient numerators between 0 and 2^-100
+    edge = np.array([0.9, 0.97, 0.98, 0.985, 0.99, 0.993, 0.996, 0.999, 0.9999, 1.0, 1.0005], dtype=np.float32)
+    cxs, cys = np.meshgrid(np.concatenate([edge, -edge]) * np.float32(d.bump_half_x), np.concatenate([edge, -edge]) * np.float32(d.bump_half_y))
+    dxs, dys = np.concatenate([dxs, cxs.ravel()]), np.concatenate([dys, cys.ravel()])
     B, C = dxs.size, d.n_cars
     ws = np.zeros((B, C, 4), dtype=np.float32)
     ws[:, 0, 0], ws[:, 0, 1], ws[:, 0, 3] = dxs, dys, np.pi / 2          # the ego at rest at (dx, dy)
