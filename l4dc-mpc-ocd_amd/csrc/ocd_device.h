@@ -336,7 +336,9 @@ __device__ __forceinline__ float reward_state(const ocd_scenario_desc &d, const 
 // that only skip +-0 terms: the full evaluation's result bit for bit, at 15 divisions and 4 exponentials per
 // lane-step instead of 17 + 6 per scripted car.  This is the common multi-feature case of the scenarios whose
 // fence region overlaps a car's collision box (replanning: x in (0.05, 0.08); merging: x in (0.1, 0.18)).
-template <int NO, int L, bool GRAD>
+// FASTDIV (GRAD only): precondition as reward_one's -- every live fence lane has |x| < LaneGradConst::x_hi (the other
+// lanes' fence units have u = shape * 0.01 or shape * (width + [0, 2 fence_lo]), inside the guard by x_hi's conditions).
+template <int NO, int L, bool GRAD, bool FASTDIV = false>
 __device__ __forceinline__ float reward_fc(const ocd_scenario_desc &d, const float (&w)[OCD_MAX_FEATURES],
                                            float x, float y, float v, float sn, float cn,
                                            const BumpGeom (&bg)[NO > 0 ? NO : 1], const bool (&nc)[NO > 0 ? NO : 1], Q4 &q,
@@ -396,7 +398,14 @@ __device__ __forceinline__ float reward_fc(const ocd_scenario_desc &d, const flo
     const float eb1 = exp_le1(mb1 + 1.0f), eb2 = exp_le1(mb2 + 1.0f), ef1 = exp_le1(mf1), ef2 = exp_le1(mf2);
 #else
     const v2f UB = {ub1, ub2}, UF = {uf1, uf2};
-    const v2f MB = div2_(splat2(-1.0f), UB), MF = div2_(splat2(-1.0f), UF);
+    v2f MB, MF, KB, KF;
+    if constexpr (FASTDIV && GRAD) {
+        recip_pair_guarded(UB, MB, KB);
+        recip_pair_guarded(UF, MF, KF);
+    } else {
+        MB = div2_(splat2(-1.0f), UB);
+        MF = div2_(splat2(-1.0f), UF);
+    }
     const v2f EB = exp_le1_2(MB + splat2(1.0f), pkc), EF = exp_le1_2(MF, pkc);
     const float mb1 = MB.x, mb2 = MB.y, mf1 = MF.x, mf2 = MF.y, eb1 = EB.x, eb2 = EB.y, ef1 = EF.x, ef2 = EF.y;
 #endif
@@ -449,7 +458,7 @@ __device__ __forceinline__ float reward_fc(const ocd_scenario_desc &d, const flo
     const float qbx = g_znx / g.wx, qby = g_zny / g.wy;
     const float q1 = g_Ssum / den, q2 = (-Ssum) / den;
 #else
-    const v2f KB = div2_(-MB, UB), KF = div2_(-MF, UF);
+    if constexpr (!(FASTDIV && GRAD)) { KB = div2_(-MB, UB); KF = div2_(-MF, UF); }
     const float kf1 = KF.x, kf2 = KF.y;
     v2f GXY;
     {
@@ -492,7 +501,7 @@ __device__ __forceinline__ float reward_fc(const ocd_scenario_desc &d, const flo
 // reward_fc).  11 packed + 1 scalar divisions and 3 packed exponentials per lane-step instead of 23 + 6 scalar ones:
 // this is the evaluation of a pass in which some lane sits inside BOTH cars' collision boxes -- most passes of the
 // slowest wavefronts of the replanning scenario, whose two scripted cars start at the same place.
-template <int L, bool GRAD>
+template <int L, bool GRAD, bool FASTDIV = false>
 __device__ __forceinline__ float reward_fcc(const ocd_scenario_desc &d, const float (&w)[OCD_MAX_FEATURES],
                                             float x, float y, float v, float sn, float cn,
                                             const BumpGeom (&bg)[2], Q4 &q, const PkConsts &pkc)
@@ -538,7 +547,16 @@ __device__ __forceinline__ float reward_fcc(const ocd_scenario_desc &d, const fl
     const bool pos2 = xd2 > 0.0f;
     const float uf2 = d.fence_shape * (pos2 ? xd2 : (0.0f + 0.01f));
     const v2f UF = {uf1, uf2};
-    const v2f MBX = div2_(splat2(-1.0f), UBX), MBY = div2_(splat2(-1.0f), UBY), MF = div2_(splat2(-1.0f), UF);
+    v2f MBX, MBY, MF, KBX, KBY, KF;
+    if constexpr (FASTDIV && GRAD) {               // (precondition: reward_fc's)
+        recip_pair_guarded(UBX, MBX, KBX);
+        recip_pair_guarded(UBY, MBY, KBY);
+        recip_pair_guarded(UF, MF, KF);
+    } else {
+        MBX = div2_(splat2(-1.0f), UBX);
+        MBY = div2_(splat2(-1.0f), UBY);
+        MF = div2_(splat2(-1.0f), UF);
+    }
     const v2f EBX = exp_le1_2(MBX + splat2(1.0f), pkc), EBY = exp_le1_2(MBY + splat2(1.0f), pkc), EF = exp_le1_2(MF, pkc);
     const float bxv0 = cx0 ? EBX.x : 0.0f, bxv1 = cx1 ? EBX.y : 0.0f;
     const float byv0 = cy0 ? EBY.x : 0.0f, byv1 = cy1 ? EBY.y : 0.0f;
@@ -580,7 +598,7 @@ __device__ __forceinline__ float reward_fcc(const ocd_scenario_desc &d, const fl
     const v2f SH = {(col0 == pcol) ? col_share : 0.0f, (col1 == pcol) ? col_share : 0.0f};
     const float g_Ssum = w_f * ax;
     const float g_ax = w_f * Ssum;
-    const v2f KBX = div2_(-MBX, UBX), KBY = div2_(-MBY, UBY), KF = div2_(-MF, UF);
+    if constexpr (!(FASTDIV && GRAD)) { KBX = div2_(-MBX, UBX); KBY = div2_(-MBY, UBY); KF = div2_(-MF, UF); }
     // bump_bwd of the four units: ((share * other axis' bump) * e) * k, (-.) * 2, * xc
     v2f GX, GY;
     {
@@ -620,13 +638,13 @@ __device__ __forceinline__ float reward_fcc(const ocd_scenario_desc &d, const fl
 }
 
 // every feature of every lane: the packed evaluation where there is one (two scripted cars), else reward_state
-template <int NO, int L, bool GRAD>
+template <int NO, int L, bool GRAD, bool FASTDIV = false>
 __device__ __forceinline__ float reward_every(const ocd_scenario_desc &d, const float (&w)[OCD_MAX_FEATURES],
                                               float x, float y, float v, float sn, float cn,
                                               const BumpGeom (&bg)[NO > 0 ? NO : 1], Q4 &q, const PkConsts &pkc)
 {
 #ifndef OCD_NO_PACKED
-    if constexpr (NO == 2 && L > 0) return reward_fcc<L, GRAD>(d, w, x, y, v, sn, cn, bg, q, pkc);
+    if constexpr (NO == 2 && L > 0) return reward_fcc<L, GRAD, FASTDIV>(d, w, x, y, v, sn, cn, bg, q, pkc);
     else
 #endif
     return reward_state<NO, L, GRAD>(d, w, x, y, v, sn, cn, bg, q, nullptr, true, true);
@@ -642,7 +660,8 @@ __device__ __forceinline__ float reward_every(const ocd_scenario_desc &d, const 
 // positive (and xd2 <= width).  With shape * fence_lo >= 2^-5, 2^-5 <= shape * width <= 2^39 and
 // 2^-31 <= shape * 0.01 <= 2^39 (checked here, once per kernel) every such denominator is >= 2^-31 and u2 <= 2^39;
 // u1 <= shape * |x| < 2^38 (1 + 2^-22) is the per-pass test.  On the other lanes the denominators are 1 - xc^2 with
-// xc^2 < 1 in fp32, i.e. in [2^-24, 1].
+// xc^2 < 1 in fp32, i.e. in [2^-24, 1]; where an evaluation runs the fence units on a lane outside the fence region
+// (reward_fc, reward_fcc) theirs are shape * 0.01 and shape * (width + [0, 2 fence_lo]) <= 3 * 2^39 / 2 (a <= 2^39 too).
 template <int L>
 struct LaneGradConst { float g0[L > 0 ? L : 1], g1[L > 0 ? L : 1]; float x_hi; };
 
@@ -653,7 +672,7 @@ __device__ __forceinline__ LaneGradConst<L> lane_grad_const(const float (&w)[OCD
     {
         const float a = d.fence_shape * d.fence_lo, b = d.fence_shape * d.fence_width, k = d.fence_shape * (0.0f + 0.01f);
         const float lo5 = 0.03125f, hi39 = 549755813888.0f, lo31 = 4.656612873077392578125e-10f;
-        const bool ok = a >= lo5 && b >= lo5 && b <= hi39 && k >= lo31 && k <= hi39;      // (false for NaN)
+        const bool ok = a >= lo5 && a <= hi39 && b >= lo5 && b <= hi39 && k >= lo31 && k <= hi39;      // (false for NaN)
         c.x_hi = ok ? 274877906944.0f / d.fence_shape : 0.0f;
     }
 #pragma unroll
