@@ -144,7 +144,16 @@ def spawn_ranks(args):
     return subprocess.run(cmd, env=env).returncode
 
 
-def plumbing_check(args, world, rank):
+def claim_stdout():
+    """stdout carries ONE line.  Everything else that anything writes to file descriptor 1 -- RCCL prints a version banner
+    there when its first communicator comes up -- goes to stderr from here on; the returned file is the real stdout."""
+    sys.stdout.flush()
+    line_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return line_out
+
+
+def plumbing_check(args, world, rank, line_out):
     """Launcher rehearsal without a GPU (tests/test_bench_launcher.py): the ranks meet over gloo, check
     the world size and gather one value each."""
     import torch
@@ -158,7 +167,7 @@ def plumbing_check(args, world, rank):
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps({"plumbing": True, "n_gpus": world, "torch": torch.__version__, "scaling": args.scaling,
-                          "emulate_rank": args.emulate_rank or None}))
+                          "emulate_rank": args.emulate_rank or None}), file=line_out, flush=True)
 
 
 def main():
@@ -200,8 +209,9 @@ def main():
     emulate = parse_emulate(args.emulate_rank) if args.emulate_rank else None
     if emulate and world != 1:
         raise SystemExit("--emulate-rank runs on one GPU (--gpus 1)")
+    line_out = claim_stdout()
     if args.plumbing_check:
-        return plumbing_check(args, world, rank)
+        return plumbing_check(args, world, rank, line_out)
 
     import torch
     import torch.distributed as dist
@@ -561,7 +571,7 @@ def main():
         coll["in_timed_step"] = True
     if rank == 0:
         out["collective"] = coll
-        print(json.dumps(out))
+        print(json.dumps(out), file=line_out, flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -15,9 +15,10 @@ def test_bench_json_line():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    # stdout is the JSON line and nothing else: what libraries print to file descriptor 1 (RCCL's version banner when the
+    # one-rank group comes up) goes to stderr (bench.py: claim_stdout)
+    assert r.stdout.count("\n") == 1 and r.stdout.startswith("{"), r.stdout[:400]
+    d = json.loads(r.stdout)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "cma_generation_ms", "config2",
               "config4_share8", "config5_share8", "reference_h5", "reference_h6_extra", "collective"):
