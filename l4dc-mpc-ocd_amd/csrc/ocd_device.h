@@ -661,7 +661,8 @@ __device__ __forceinline__ float reward_every(const ocd_scenario_desc &d, const 
 // 2^-31 <= shape * 0.01 <= 2^39 (checked here, once per kernel) every such denominator is >= 2^-31 and u2 <= 2^39;
 // u1 <= shape * |x| < 2^38 (1 + 2^-22) is the per-pass test.  On the other lanes the denominators are 1 - xc^2 with
 // xc^2 < 1 in fp32, i.e. in [2^-24, 1]; where an evaluation runs the fence units on a lane outside the fence region
-// (reward_fc, reward_fcc) theirs are shape * 0.01 and shape * (width + [0, 2 fence_lo]) <= 3 * 2^39 / 2 (a <= 2^39 too).
+// (reward_fc, reward_fcc) theirs are shape * 0.01 and shape * (width + [0, 2 fence_lo]) <= 3 * 2^39 (a <= 2^39 too) --
+// all far inside what recip_pair_guarded needs.
 template <int L>
 struct LaneGradConst { float g0[L > 0 ? L : 1], g1[L > 0 ? L : 1]; float x_hi; };
 

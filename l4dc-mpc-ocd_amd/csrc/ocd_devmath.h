@@ -130,12 +130,13 @@ __device__ __forceinline__ v2f div2_(v2f n, v2f d)
     return out;
 }
 
-// m = -1/d and k = (-m)/d (= div2_(splat2(-1), d) and div2_(-m, d)) for denominators the CALLER has shown to lie in
-// [2^-32, 2^40]: there v_div_scale_f32 returns both operands of both divisions unchanged with VCC = 0 (numerators -1 and
-// 1/d: no exponent difference near +-96 / -126, nothing denormal), v_div_fmas_f32 is the plain fma and v_div_fixup_f32
-// passes the quotient through -- so the two divisions are the operations below, the SAME operations on the same values
-// as div2_'s, with the scaling / fix-up instructions (identities) left out and ONE reciprocal refinement serving both
-// (same denominator -> same v_rcp_f32, same two fma).  17 issue slots instead of 38.
+// m = -1/d and k = (-m)/d (= div2_(splat2(-1), d) and div2_(-m, d)) for denominators the CALLER has shown to lie well
+// inside [2^-46, 2^62] (the callers' bounds: [2^-32, 2^41]): there v_div_scale_f32 returns both operands of both divisions
+// unchanged with VCC = 0 -- the numerators are -1 and 1/d: neither exponent difference reaches 96 or -126, nothing is
+// denormal, no numerator is below 2^-103 --, v_div_fmas_f32 is the plain fma and v_div_fixup_f32 passes the quotient
+// through.  So the two divisions are the operations below, the SAME operations on the same values as div2_'s, with the
+// scaling / fix-up instructions (identities) left out and ONE reciprocal refinement serving both (same denominator ->
+// same v_rcp_f32, same two fma).  17 issue slots instead of 38.
 __device__ __forceinline__ void recip_pair_guarded(v2f d, v2f &m, v2f &k)
 {
     v2f r, r1, e, q;
