@@ -333,6 +333,14 @@ int32_t ocd_debug_packed_math(const float *num, const float *den, const float *x
                               float *div_packed_out, float *exp_scalar_out, float *exp_packed_out, int64_t n_pairs,
                               void *hip_stream);
 
+/* The shortened divisions of the reward features (csrc/ocd_devmath.h: recip_pair_guarded, quot2_by_recip with
+ * refined_recip) on caller-supplied operands, so that the tests can hold them against correctly rounded division over the
+ * whole operand range their guards admit (and see where they stop being exact beyond it).  All arrays hold 2 * n_pairs
+ * floats.  u -> m_out = -1/u, k_out = (-m)/u;  (n, w) -> q_out = n / w through the refined reciprocal of w.  u or (n, w)
+ * may be NULL to skip that half. */
+int32_t ocd_debug_guarded_division(const float *u, const float *n, const float *w, float *m_out, float *k_out,
+                                   float *q_out, int64_t n_pairs, void *hip_stream);
+
 /* Block until everything queued on `hip_stream` (NULL = the default stream) has finished: hipStreamSynchronize behind
  * the C ABI, for host code that holds no HIP headers -- the native CMA-ES generation loop of include/ocd_cma.h waits for
  * its episode launch through this (mpc_ord.py:41: pycma's serial loop around the fitness callable). */

@@ -590,6 +590,19 @@ int32_t ocd_debug_packed_math(const float *num, const float *den, const float *x
     return OCD_OK;
 }
 
+int32_t ocd_debug_guarded_division(const float *u, const float *n, const float *w, float *m_out, float *k_out,
+                                   float *q_out, int64_t n_pairs, void *hip_stream)
+{
+    if (n_pairs < 0 || (n_pairs > 0 && !(u || (n && w))) || ((n == nullptr) != (w == nullptr)))
+        return fail(OCD_ERR_INVALID_ARG, "bad arguments");
+    if (n_pairs == 0) return OCD_OK;
+    int32_t st = need_device();
+    if (st != OCD_OK) return st;
+    hipError_t e = ocd::launch_guarded_division(u, n, w, m_out, k_out, q_out, n_pairs, (hipStream_t)hip_stream);
+    if (e != hipSuccess) return hip_fail(e, "guarded_division_kernel launch");
+    return OCD_OK;
+}
+
 int32_t ocd_time_rollout(const ocd_scenario *scn, const float *init_states, const float *cand_weights,
                          int64_t P, int64_t N, int64_t ep_begin, int64_t ep_end,
                          float *returns_out, int32_t reps, float *ms_out, void *hip_stream)

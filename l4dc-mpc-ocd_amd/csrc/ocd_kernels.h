@@ -135,6 +135,8 @@ hipError_t launch_objective(int NO, int L, const KernelParams &p, const float *c
 hipError_t launch_math(const float *in, float *e, float *s, float *c, long long n, hipStream_t st);
 hipError_t launch_packed_math(const float *num, const float *den, const float *x, float *div_scalar, float *div_packed,
                               float *exp_scalar, float *exp_packed, long long n_pairs, hipStream_t st);
+hipError_t launch_guarded_division(const float *u, const float *n, const float *w, float *m_out, float *k_out, float *q_out,
+                                   long long n_pairs, hipStream_t st);
 hipError_t launch_dynamics(const float *states, const float *controls, float dt, float dt_sq, float friction,
                            float *out, long long n, hipStream_t st);
 

@@ -1011,6 +1011,25 @@ __global__ void packed_math_kernel(const float *num, const float *den, const flo
     }
 }
 
+// the shortened divisions on caller-supplied operands (ocd_debug_guarded_division)
+__global__ void guarded_division_kernel(const float *u, const float *n, const float *w, float *m_out, float *k_out,
+                                        float *q_out, long long n_pairs)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pairs) return;
+    if (u) {
+        v2f m, k;
+        recip_pair_guarded(v2f{u[2 * i], u[2 * i + 1]}, m, k);
+        if (m_out) { m_out[2 * i] = m.x; m_out[2 * i + 1] = m.y; }
+        if (k_out) { k_out[2 * i] = k.x; k_out[2 * i + 1] = k.y; }
+    }
+    if (n && w) {
+        const v2f ww{w[2 * i], w[2 * i + 1]};
+        const v2f q = quot2_by_recip(v2f{n[2 * i], n[2 * i + 1]}, ww, v2f{refined_recip(ww.x), refined_recip(ww.y)});
+        if (q_out) { q_out[2 * i] = q.x; q_out[2 * i + 1] = q.y; }
+    }
+}
+
 } // namespace ocd
 
 // ---------------------------------------------------------------- launch table
@@ -1202,6 +1221,15 @@ hipError_t launch_packed_math(const float *num, const float *den, const float *x
     const unsigned nb = (unsigned)((n_pairs + bs - 1) / bs);
     hipLaunchKernelGGL(packed_math_kernel, dim3(nb), dim3(bs), 0, st, num, den, x, div_scalar, div_packed, exp_scalar,
                        exp_packed, n_pairs);
+    return hipGetLastError();
+}
+
+hipError_t launch_guarded_division(const float *u, const float *n, const float *w, float *m_out, float *k_out, float *q_out,
+                                   long long n_pairs, hipStream_t st)
+{
+    const unsigned bs = 64;
+    const unsigned nb = (unsigned)((n_pairs + bs - 1) / bs);
+    hipLaunchKernelGGL(guarded_division_kernel, dim3(nb), dim3(bs), 0, st, u, n, w, m_out, k_out, q_out, n_pairs);
     return hipGetLastError();
 }
 

@@ -80,6 +80,19 @@ class DeviceOps:
         return tuple(o.cpu().numpy() for o in outs)
 
 
+    def debug_guarded_division(self, u, n, w):
+        """(m, k, q): m = -1/u and k = (-m)/u by recip_pair_guarded, q = n / w by quot2_by_recip, of 2 * n_pairs
+        operands each (include/ocd.h: ocd_debug_guarded_division)."""
+        uu, nn, ww = (self._to_dev(a).reshape(-1) for a in (u, n, w))
+        if not (uu.numel() == nn.numel() == ww.numel()) or uu.numel() % 2:
+            raise ValueError("u, n and w must hold the same even number of floats")
+        outs = [torch.empty_like(uu) for _ in range(3)]
+        self._call(self.lib.ocd_debug_guarded_division, _ptr(uu), _ptr(nn), _ptr(ww), *[_ptr(o) for o in outs],
+                   uu.numel() // 2, self._stream())
+        torch.cuda.synchronize(self.device)
+        return tuple(o.cpu().numpy() for o in outs)
+
+
 _default_ops: Optional[DeviceOps] = None
 
 
