@@ -155,10 +155,17 @@ void base_params(const ocd_scenario *scn, ocd::KernelParams &p)
     p.K = scn->K;
     p.S = scn->desc.n_samples;
     p.segs_used = scn->opt_segs;
-    p.no_skips = scn->opt_no_skips;
+    // Skipping the fence feature on a lane outside the fence region (|x| <= fence_lo) rests on S(x) = F1 / (F1 + F2) being
+    // EXACTLY 0 there: F1 = 0 and F2 = exp(-1 / (shape * (width - xd))) > 0 with width - xd >= width.  exp flushes to 0 below
+    // exp(-87), so that needs shape * width >= 1/87 (the reference's smooth_threshold has shape * width = c = 5 always,
+    // math_utils.py:88-95).  A descriptor below that makes S = 0/0 = NaN everywhere, as in the reference: every feature of
+    // every lane is evaluated then, as with the "no_feature_skips" option.
+    const bool fence_degenerate = !(scn->desc.fence_shape * scn->desc.fence_width >= 0.0125f);
+    const bool no_skips = scn->opt_no_skips || (scn->desc.reward_kind == OCD_REWARD_LANE_FEATURES && fence_degenerate);
+    p.no_skips = no_skips;
     p.scan_mode = scn->opt_scan_mode;
     p.no_unify = scn->opt_no_unify;
-    p.force_full = scn->opt_no_skips ? ~0ull : 0ull;
+    p.force_full = no_skips ? ~0ull : 0ull;
     p.force_full_any = scn->opt_no_unify ? ~0ull : 0ull;
     p.no_latency_build = scn->opt_no_lat;
     p.reset_phase = scn->opt_reset_phase;

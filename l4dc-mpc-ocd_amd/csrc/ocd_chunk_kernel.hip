@@ -218,18 +218,24 @@ mpc_chunk_kernel(const KernelParams p)
         // one scripted car: the refined reciprocals of its half-widths in this control step (reward_one's FASTDIV form divides by
         // them in every pass) and the lanes whose widths are outside its guard
         BumpRecip br[S][NOA];
-        unsigned long long widths_beyond = 0ull;
+        unsigned long long widths_beyond = 0ull, widths_degenerate = 0ull;
 #pragma unroll
         for (int s = 0; s < S; ++s)
 #pragma unroll
             for (int j = 0; j < NOA; ++j) {
                 br[s][j] = BumpRecip{0.0f, 0.0f};
+                if constexpr (lane_feats && NO > 0)
+                    widths_degenerate |= __builtin_amdgcn_ballot_w64(bump_widths_degenerate(bg[s][j])) & ((s >= SL) ? real_mask : live_mask);
                 if constexpr (lane_feats && NO == 1) {
                     br[s][j].rx = refined_recip(bg[s][j].wx);
                     br[s][j].ry = refined_recip(bg[s][j].wy);
                     widths_beyond |= __builtin_amdgcn_ballot_w64(!bump_widths_guarded(bg[s][j]));
                 }
             }
+        // a degenerate width (ocd_device.h: bump_widths_degenerate) sends every pass of this control step to the evaluation of
+        // every feature: through `beyond` in the straight-line builds, as the "no_feature_skips" knob does in the others
+        widths_beyond |= widths_degenerate;
+        const bool full_step = p.no_skips || widths_degenerate != 0ull;
 
         // ---- control initialisation of this segment (naive_planner.py:107-116) ----
         float s0, c0;
@@ -382,7 +388,7 @@ mpc_chunk_kernel(const KernelParams p)
                     OCD_STAMP(4);                          // choice of the evaluation
                     if (__builtin_expect((multi_f | multi_c | beyond) != 0ull, 0)) {
                         if (__builtin_expect(beyond != 0ull, 0)) {
-                            if (multi_c != 0ull)
+                            if ((multi_c | widths_degenerate) != 0ull)
                                 rw[s] = reward_every<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], q[s], pkc);
                             else if (multi_f != 0ull)
                                 rw[s] = reward_fc<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], nc, q[s], pkc);
@@ -427,7 +433,7 @@ mpc_chunk_kernel(const KernelParams p)
                         }
                         const bool has_f = mf != 0ull, has_col = mc_any != 0ull;
                         OCD_STAMP(4);                      // choice of the evaluation
-                        if (p.no_skips || multi_c != 0ull || (p.no_unify && (has_f || has_col))) {
+                        if (full_step || multi_c != 0ull || (p.no_unify && (has_f || has_col))) {
                             // (reward_every's packed form needs more registers than these builds have to spare)
                             rw[s] = reward_state<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], q[s], nullptr, true, true);
                             OCD_STAMP(5); OCD_STAMP_COUNT(12);

@@ -157,6 +157,15 @@ __device__ __forceinline__ bool bump_widths_guarded(const BumpGeom &g)
     return g.wx >= lo && g.wx <= hi && g.wy >= lo && g.wy <= hi;
 }
 
+// Skipping a car's collision feature on a lane outside its box rests on the skipped adjoint g_zn / width being exactly
+// +-0 (g_zn = 0 there): true for a finite, non-zero width.  A half-width that rounds away against the car's position
+// ((o + h) - (o - h) = 0) or a non-finite position makes it 0/0 or 0/NaN = NaN in the full evaluation: such a control step
+// evaluates every feature of every lane.
+__device__ __forceinline__ bool bump_widths_degenerate(const BumpGeom &g)
+{
+    return !(g.wx > 0.0f && g.wx <= 3.4028234663852886e38f && g.wy > 0.0f && g.wy <= 3.4028234663852886e38f);
+}
+
 struct Q4 { float qx, qy, qv, qth; };
 
 // The kernels' template parameter L: > 0 = lane-feature reward with L lanes, 0 = target-speed test reward,

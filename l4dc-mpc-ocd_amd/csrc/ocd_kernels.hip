@@ -310,16 +310,21 @@ mpc_kernel(const KernelParams p)
         // one scripted car: the refined reciprocals of its half-widths in this control step (reward_one's FASTDIV form divides by
         // them in every pass) and the lanes whose widths are outside its guard
         BumpRecip br[NOA];
-        unsigned long long widths_beyond = 0ull;
+        unsigned long long widths_beyond = 0ull, widths_degenerate = 0ull;
 #pragma unroll
         for (int j = 0; j < NOA; ++j) {
             br[j] = BumpRecip{0.0f, 0.0f};
+            if constexpr (lane_feats && NO > 0) widths_degenerate |= __builtin_amdgcn_ballot_w64(bump_widths_degenerate(bg[j])) & feat_mask;
             if constexpr (lane_feats && NO == 1) {
                 br[j].rx = refined_recip(bg[j].wx);
                 br[j].ry = refined_recip(bg[j].wy);
                 widths_beyond |= __builtin_amdgcn_ballot_w64(!bump_widths_guarded(bg[j]));
             }
         }
+        // a degenerate width (ocd_device.h: bump_widths_degenerate) sends every pass of this control step to the evaluation of
+        // every feature: through `beyond` in the straight-line builds, through the knob mask in the others
+        widths_beyond |= widths_degenerate;
+        const unsigned long long force_full_step = force_full | widths_degenerate;
 
         // ---- this lane's control initialisation (naive_planner.py:107-116) ----
         float s0, c0;
@@ -518,7 +523,7 @@ mpc_kernel(const KernelParams p)
                     // passes of the slowest wavefronts): decided before the evaluation, one evaluation per pass
                     if (__builtin_expect((multi_f | multi_c | beyond) != 0ull, 0)) {
                         if (__builtin_expect(beyond != 0ull, 0)) {
-                            if (multi_c != 0ull) r = reward_every<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, pkc);
+                            if ((multi_c | widths_degenerate) != 0ull) r = reward_every<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, pkc);
                             else if (multi_f != 0ull) r = reward_fc<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, nc, q, pkc);
                             else r = reward_one<NO, L, GRAD, false, phi0_in_chain>(d, w, xn, yn, vn, sn, cn, bg, br, nc, nf, true, true, q, pkc, lgc, feat_mask);
                         } else if (multi_c != 0ull) r = reward_every<NO, L, GRAD, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, pkc);
@@ -535,15 +540,15 @@ mpc_kernel(const KernelParams p)
                     r = reward_one<NO, L, GRAD, false, phi0_in_chain, GRAD>(d, w, xn, yn, vn, sn, cn, bg, br, nc, nf, true, true, q, pkc, lgc, feat_mask);
                     OCD_STAMP(6); OCD_STAMP_COUNT(13);     // one feature per lane
                     if (__builtin_expect((multi_f | multi_c | beyond) != 0ull, 0)) {
-                        if (multi_c != 0ull) r = reward_every<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, pkc);
+                        if ((multi_c | widths_degenerate) != 0ull) r = reward_every<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, pkc);
                         else if (multi_f != 0ull) r = reward_fc<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, nc, q, pkc);
                         else r = reward_one<NO, L, GRAD, false, phi0_in_chain>(d, w, xn, yn, vn, sn, cn, bg, br, nc, nf, true, true, q, pkc, lgc, feat_mask);
                         OCD_STAMP(5); OCD_STAMP_COUNT(12); // every feature / fence + one car per lane / full divisions
                     }
                 } else {
                     // (the diagnostics knobs enter as two wave-uniform masks: two scalar tests decide the path)
-                    const unsigned long long full_m = multi_c | force_full | (any_feat & force_full_any);
-                    if (__builtin_expect((any_feat | force_full) != 0ull, 1)) {
+                    const unsigned long long full_m = multi_c | force_full_step | (any_feat & force_full_any);
+                    if (__builtin_expect((any_feat | force_full_step) != 0ull, 1)) {
                         if (__builtin_expect(full_m != 0ull, 0)) {
                             r = reward_state<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, true, true);
                             OCD_STAMP(5); OCD_STAMP_COUNT(12);     // every feature

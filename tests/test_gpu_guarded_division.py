@@ -129,3 +129,55 @@ def test_zero_and_tiny_bump_numerators_bitwise(hip, oracle, name, H, mode, no_la
     for k in ("all_losses", "all_plans", "plans", "best_loss"):
         assert same(out[k], ref[k]), (name, H, mode, k)
     assert np.array_equal(out["best_init"], ref["best_init"])
+
+
+EXTREME = [  # (fence_lo, fence_width, fence_shape or None = 5 / width, bump_half_x, bump_half_y)
+    (1e-30, 0.05, None, 0.08, 0.15), (1e-8, 0.05, None, 0.08, 0.15), (3.0e-4, 0.05, None, 0.08, 0.15),
+    (3.2e-4, 0.05, None, 0.08, 0.15), (0.1, 1e-6, None, 0.08, 0.15), (0.1, 1e-3, None, 0.08, 0.15), (0.1, 10.0, None, 0.08, 0.15),
+    (0.1, 0.05, 1e-3, 0.08, 0.15), (0.1, 0.05, 1e6, 0.08, 0.15), (0.1, 0.05, 1e12, 0.08, 0.15), (0.1, 0.05, 3e13, 0.08, 0.15),
+    (0.1, 0.05, None, 1e-7, 0.15), (0.1, 0.05, None, 9e-7, 0.15), (0.1, 0.05, None, 1e-6, 1e-6), (0.1, 0.05, None, 0.08, 1e6),
+    (0.1, 0.05, None, 2e6, 0.15), (0.1, 0.05, None, 1e6, 2e6), (1e3, 1e3, None, 0.08, 0.15), (0.1, 0.05, None, 1e-30, 1e30),
+]
+
+
+@pytest.mark.parametrize("no_lat", [0, 1])
+@pytest.mark.parametrize("case", range(len(EXTREME)))
+@pytest.mark.parametrize("name,H,mode", [("local_opt", 10, 3), ("finite_horizon", 5, 2), ("merging", 10, 4), ("replanning", 5, 0)])
+def test_descriptors_at_and_beyond_the_static_guards_bitwise(hip, oracle, name, H, mode, case, no_lat):
+    """Fences and collision boxes whose parameters sit on both sides of the conditions under which the shortened divisions
+    are allowed at all (LaneGradConst::x_hi: shape * fence_lo >= 2^-5, shape * width in [2^-5, 2^39], shape * 0.01 in
+    [2^-31, 2^39]; bump half-widths in [2^-20, 2^20]): wherever a condition fails the full divisions must run."""
+    from l4dc_mpc_ocd_amd.engine import Engine
+    lo, width, shape, hx, hy = EXTREME[case]
+    base = scenarios.SCENARIOS[name](horizon=H)
+    d = abi.ScenarioDesc.from_buffer_copy(bytes(base.desc))
+    d.n_iter = 3
+    d.fence_lo, d.fence_width = lo, width
+    d.fence_shape = float(np.float32(5.0) / np.float32(width)) if shape is None else shape
+    d.bump_half_x, d.bump_half_y = hx, hy
+    scn = scenarios.Scenario(base.name + "_extreme", d, base.init_dist, None)
+    lo32, w32_ = np.float32(d.fence_lo), np.float32(d.fence_width)
+    xs = [np.float32(0.0), lo32, np.nextafter(lo32, np.float32(np.inf)), lo32 * np.float32(1.0001), lo32 + w32_ * np.float32(0.5),
+          lo32 + w32_, np.nextafter(lo32 + w32_, np.float32(0)), lo32 + w32_ * np.float32(3), np.float32(0.01), np.float32(0.07),
+          np.float32(0.2), np.float32(1e-20), np.float32(5.0), np.float32(1e8), np.float32(1e20)]
+    xs = np.array(xs + [-x for x in xs], dtype=np.float32)
+    dys = np.array([0.0, 0.3, 0.99, 1.0, 1.5], dtype=np.float32) * np.float32(min(d.bump_half_y, 1e3))
+    X, DY = np.meshgrid(xs, dys)
+    X, DY = X.ravel(), DY.ravel()
+    B, C = X.size, d.n_cars
+    ws = np.zeros((B, C, 4), dtype=np.float32)
+    ws[:, 0, 0], ws[:, 0, 1], ws[:, 0, 3] = X, np.float32(-0.9) + DY, np.pi / 2
+    ws[:, 1] = np.array([0.07, -0.9, 0.0, np.pi / 2], dtype=np.float32)       # a resting car: centre inside the fence region
+    for j in range(2, C):
+        ws[:, j] = np.array(d.other_init[j - 1][:], dtype=np.float32)
+    w = scenarios.planner_weights_fp32(base.candidate_weights(1, seed=4)[0])
+    eng = Engine(scn, "cuda:0")
+    eng.set_option("scan_mode", mode)
+    eng.set_option("no_latency_build", no_lat)
+    if mode == 4:
+        eng.set_option("chunk_size", 5)
+    out = eng.plan_batch(ws, w, want_all=True)
+    ref = oracle.plan_batch(d, ws, w, other_plans=scn.other_plans())
+    for k in ("all_losses", "all_plans", "plans", "best_loss"):
+        assert same(out[k], ref[k]), (name, H, mode, EXTREME[case], k)
+    assert np.array_equal(out["best_init"], ref["best_init"])
