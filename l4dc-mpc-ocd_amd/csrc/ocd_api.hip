@@ -89,6 +89,14 @@ int32_t validate(const ocd_scenario_desc *d)
             if (d->teleport_car[s] >= d->n_cars)
                 return fail(OCD_ERR_INVALID_ARG, "teleport_car[%d] = %d >= n_cars", s, d->teleport_car[s]);
     if (!(d->dt > 0.0f)) return fail(OCD_ERR_INVALID_ARG, "dt must be > 0");
+    // smooth_threshold(x) = F1 / (F1 + F2), F = exp(-1 / (shape * .)): on the road side of the fence F1 = 0 and
+    // F2 = exp(-1 / (shape * (width - xd))) with width - xd >= width.  The reference always has shape * width = c = 5
+    // (math_utils.py:88-95, merging.py:80).  Below 1/87 F2 flushes to 0 as well and the feature is 0/0 = NaN on the road
+    // itself; every evaluation of the kernels (ocd_device.h: reward_state and the forms derived from it) evaluates ONE side of
+    // the fence per lane and takes the other as exactly 0, which that NaN would break: refused rather than answered wrongly.
+    if (d->reward_kind == OCD_REWARD_LANE_FEATURES && !(d->fence_shape * d->fence_width >= 0.0125f))
+        return fail(OCD_ERR_UNSUPPORTED, "fence_shape * fence_width = %g < 1/80: smooth_threshold is 0/0 on the road (the reference's is 5)",
+                    (double)(d->fence_shape * d->fence_width));
     if (d->reward_kind == OCD_REWARD_LANE_FEATURES && !(d->fence_lo >= 0.0f && d->fence_width > 0.0f))
         return fail(OCD_ERR_INVALID_ARG, "fence_lo must be >= 0 and fence_width > 0 (0.05*num_lanes - 0.05, 0.05)");
     return OCD_OK;
@@ -155,17 +163,10 @@ void base_params(const ocd_scenario *scn, ocd::KernelParams &p)
     p.K = scn->K;
     p.S = scn->desc.n_samples;
     p.segs_used = scn->opt_segs;
-    // Skipping the fence feature on a lane outside the fence region (|x| <= fence_lo) rests on S(x) = F1 / (F1 + F2) being
-    // EXACTLY 0 there: F1 = 0 and F2 = exp(-1 / (shape * (width - xd))) > 0 with width - xd >= width.  exp flushes to 0 below
-    // exp(-87), so that needs shape * width >= 1/87 (the reference's smooth_threshold has shape * width = c = 5 always,
-    // math_utils.py:88-95).  A descriptor below that makes S = 0/0 = NaN everywhere, as in the reference: every feature of
-    // every lane is evaluated then, as with the "no_feature_skips" option.
-    const bool fence_degenerate = !(scn->desc.fence_shape * scn->desc.fence_width >= 0.0125f);
-    const bool no_skips = scn->opt_no_skips || (scn->desc.reward_kind == OCD_REWARD_LANE_FEATURES && fence_degenerate);
-    p.no_skips = no_skips;
+    p.no_skips = scn->opt_no_skips;
     p.scan_mode = scn->opt_scan_mode;
     p.no_unify = scn->opt_no_unify;
-    p.force_full = no_skips ? ~0ull : 0ull;
+    p.force_full = scn->opt_no_skips ? ~0ull : 0ull;
     p.force_full_any = scn->opt_no_unify ? ~0ull : 0ull;
     p.no_latency_build = scn->opt_no_lat;
     p.reset_phase = scn->opt_reset_phase;

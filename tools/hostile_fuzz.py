@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Differential fuzz with HOSTILE descriptors and states: every float field of the descriptor drawn log-uniformly over
+many decades (or set to 0 / a huge value), weights with zeros, states far outside the road, at rest, at speed 1e3 --
+the inputs no scenario of the reference produces but the C ABI accepts.  HIP path vs CPU oracle, bit for bit (NaN = NaN).
+Found in round 4: the feature skips assumed shape * width >= 1/87 and a non-zero bump half-width.
+usage (GPU box): python tools/hostile_fuzz.py --cases 2000 [--seed 1]"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def same(a, b):
+    return a.shape == b.shape and bool(np.all((a == b) | (np.isnan(a) & np.isnan(b))))
+
+
+def logu(rng, lo, hi):
+    return float(np.exp(rng.uniform(np.log(lo), np.log(hi))))
+
+
+def pick(rng, normal, lo, hi, p_extreme=0.35):
+    """the scenario's own value most of the time, else log-uniform over [lo, hi], now and then 0"""
+    r = rng.random()
+    if r > p_extreme:
+        return normal
+    return 0.0 if r < 0.03 else logu(rng, lo, hi)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=500)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    import oracle_lib
+    from test_gpu_random_scenarios import random_scenario
+    from l4dc_mpc_ocd_amd import abi
+    from l4dc_mpc_ocd_amd.engine import Engine
+    orc = oracle_lib.load()
+    shapes = [(5, 1, 3), (6, 1, 3), (10, 1, 3), (15, 1, 3), (5, 2, 2), (10, 2, 2), (15, 2, 2), (10, 2, 3), (25, 1, 3), (25, 2, 3),
+              (7, 1, 3), (3, 3, 2), (12, 1, 1), (4, 2, 4)]
+    bad = skipped = 0
+    for case in range(a.cases):
+        rng = np.random.default_rng(100000 * a.seed + case)
+        H, NO, L = shapes[case % len(shapes)]
+        scn = random_scenario(rng, H, NO, L)
+        d = scn.desc
+        d.n_iter = int(rng.integers(0, 7))
+        d.episode_len = int(rng.integers(0, 5))
+        d.dt = pick(rng, d.dt, 1e-6, 1e3)
+        d.dt_sq = np.float32(d.dt) * np.float32(d.dt) if rng.random() < 0.8 else pick(rng, d.dt_sq, 1e-12, 1e6)
+        d.learning_rate = pick(rng, d.learning_rate, 1e-8, 1e6)
+        d.ego_friction = pick(rng, d.ego_friction, 1e-6, 1e4)
+        d.target_speed = pick(rng, d.target_speed, 1e-6, 1e6)
+        d.fence_lo = pick(rng, d.fence_lo, 1e-12, 1e4)
+        d.fence_width = pick(rng, d.fence_width, 1e-9, 1e6, 0.4) or 0.05          # (validated > 0)
+        d.fence_shape = pick(rng, float(np.float32(5.0) / np.float32(d.fence_width)), 1e-9, 1e12, 0.4)
+        if np.float32(d.fence_shape) * np.float32(d.fence_width) < 0.0125 and rng.random() < 0.85:
+            d.fence_shape = float(logu(rng, 0.0126, 50.0) / d.fence_width)       # (below 1/80 the library refuses the descriptor)
+        d.bump_half_x = pick(rng, d.bump_half_x, 1e-12, 1e8, 0.4)
+        d.bump_half_y = pick(rng, d.bump_half_y, 1e-12, 1e8, 0.4)
+        for i in range(L):
+            d.lane_center[i] = pick(rng, d.lane_center[i], 1e-9, 1e6, 0.2) * float(rng.choice([-1, 1]))
+        for j in range(NO):
+            d.other_friction[j] = pick(rng, d.other_friction[j], 1e-6, 1e4, 0.2)
+        h = abi.ScenarioDesc.from_buffer_copy(bytes(d))
+        eng = None
+        try:
+            eng = Engine(scn, "cuda:0")
+        except Exception as e:                                  # noqa: BLE001 -- a descriptor validate() rejects
+            skipped += 1
+            continue
+        mode = int(rng.choice([0, 1, 2, 3, 4]))
+        if (mode == 2 and H > 16) or (mode == 3 and d.n_ctrl_inits * H > 64) or (mode == 4 and H not in (10, 15, 25)):
+            mode = 0
+        eng.set_option("scan_mode", mode)
+        eng.set_option("no_latency_build", int(rng.integers(0, 2)))
+        B = int(rng.integers(1, 24))
+        ws = np.zeros((B, NO + 1, 4), dtype=np.float32)
+        ws[:, 0, 0] = rng.uniform(-0.3, 0.3, B); ws[:, 0, 1] = rng.uniform(-1.4, -0.5, B)
+        ws[:, 0, 2] = rng.uniform(0.0, 1.3, B); ws[:, 0, 3] = np.pi / 2 + rng.uniform(-0.6, 0.6, B)
+        for j in range(NO):
+            ws[:, j + 1] = np.array(d.other_init[j][:]) + rng.uniform(-0.05, 0.05, (B, 4))
+        k = rng.random(B)
+        ws[k < 0.15, 0, 0] *= np.float32(logu(rng, 1e-6, 1e9))                  # far off the road / denormally close to it
+        ws[(k > 0.15) & (k < 0.25), 0, 2] = np.float32(logu(rng, 1e-3, 1e4)) * rng.choice([-1, 1])
+        ws[(k > 0.25) & (k < 0.3), 0, 2] = 0.0
+        if rng.random() < 0.2:
+            ws[:, 1, :2] = ws[:, 0, :2]                                          # on top of a scripted car
+        if rng.random() < 0.1:
+            ws[:, 1, 0] = np.float32(logu(rng, 1e3, 1e30))                      # a scripted car far away (its width rounds away)
+        wts = rng.standard_normal((B, L + 4))
+        wts[:, rng.integers(0, L + 4)] = 0.0
+        w32 = (wts / np.linalg.norm(wts, axis=1, keepdims=True)).astype(np.float32)
+        ref = orc.plan_batch(d, ws, w32, other_plans=scn.other_plans())
+        out = eng.plan_batch(ws, w32, want_all=True)
+        ok = all(same(out[kk], ref[kk]) for kk in ("all_losses", "all_plans", "plans", "best_loss")) and \
+            np.array_equal(out["best_init"], ref["best_init"])
+        if d.episode_len > 0:
+            inits = ws[: min(B, 3), 0]
+            ro = eng.rollout(inits, w32[:2], want_traj=True)
+            rr = orc.rollout(d, inits, w32[:2], want_traj=True)
+            ok = ok and all(same(ro[kk], rr[kk]) for kk in ("ctrl", "traj", "returns"))
+        if not ok:
+            bad += 1
+            print(f"MISMATCH case {case} (seed {a.seed}): H={H} NO={NO} L={L} scan_mode={mode} B={B} dt={d.dt:g} lr={d.learning_rate:g} "
+                  f"fr={d.ego_friction:g} tgt={d.target_speed:g} fence=({d.fence_lo:g},{d.fence_width:g},{d.fence_shape:g}) "
+                  f"bump=({d.bump_half_x:g},{d.bump_half_y:g})", flush=True)
+        if case % 100 == 99:
+            print(f"{case + 1} cases, {bad} mismatches, {skipped} rejected descriptors", flush=True)
+    print(f"done: {a.cases} cases, {bad} mismatches, {skipped} rejected descriptors")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
