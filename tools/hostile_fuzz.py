@@ -67,6 +67,13 @@ def main():
             d.lane_center[i] = pick(rng, d.lane_center[i], 1e-9, 1e6, 0.2) * float(rng.choice([-1, 1]))
         for j in range(NO):
             d.other_friction[j] = pick(rng, d.other_friction[j], 1e-6, 1e4, 0.2)
+            if rng.random() < 0.12:                                  # scripted controls that send the car to infinity / NaN
+                for t in range(int(d.other_plan_len[j])):
+                    d.other_plan[j][t][0] = float(rng.choice([-1, 1])) * logu(rng, 1e3, 1e38)
+                    d.other_plan[j][t][1] = float(rng.choice([-1, 1])) * logu(rng, 1e-3, 1e30)
+                d.other_default[j][0] = float(rng.choice([-1, 1])) * logu(rng, 1e-3, 1e30)
+            if rng.random() < 0.08:
+                d.other_init[j][2] = logu(rng, 1e3, 1e38)            # a scripted car at absurd speed
         h = abi.ScenarioDesc.from_buffer_copy(bytes(d))
         eng = None
         try:
