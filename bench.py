@@ -409,7 +409,7 @@ def main():
             med = float(tt.item())
         return {"cma_generation_ms": med, "fitness_ms": float(np.median(fs)),
                 "generations_run": int(len(m.generation_seconds)), "generations_timed": int(len(gs)),
-                "popsize": int(m.es.lam), "n_inits": cfg["n_inits"], "stop_reason": {k: float(v) for k, v in m.stop_reason.items()},
+                "popsize": int(m.es.lam), "n_inits": cfg["n_inits"], "stop_reason": {k: (None if v is None else float(v)) for k, v in m.stop_reason.items()},
                 "n_nonfinite": int(sum(m.n_nonfinite)), "n_resampled": int(m.n_resampled),
                 "host_split_ms": m.host_split_ms(),
                 "path": "MPC_ORD.optimize_cmaes: ask (native, csrc/ocd_cma.c), host normalisation into pinned memory "

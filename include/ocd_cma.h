@@ -23,7 +23,8 @@ extern "C" {
 #endif
 
 #define OCD_CMA_MAX_DIM 64
-#define OCD_CMA_ABI_VERSION 4      /* 2: tell returns the non-finite count; resample, stop_state, abi_version; 3: normalise_weights; 4: stop, run */
+#define OCD_CMA_ABI_VERSION 5      /* 2: tell returns the non-finite count; resample, stop_state, abi_version; 3: normalise_weights; 4: stop, run; 5: 12 stop rules (noeffectaxis, noeffectcoord), add_evals */
+#define OCD_CMA_N_STOP 12          /* termination rules of ocd_cma_stop */
 
 typedef struct ocd_cma ocd_cma;
 
@@ -48,6 +49,9 @@ int32_t ocd_cma_resample(ocd_cma *es, int32_t k, double *X);
  * uses the steps behind those rows) and its costs fitness [lambda] (lower is better).  Costs are ranked with NaN LAST
  * (numpy's argsort order; +inf just before); returns the number of non-finite costs (>= 0), or -1 on bad arguments. */
 int32_t ocd_cma_tell(ocd_cma *es, const double *X, const double *fitness);
+/* Count n evaluations made outside tell: candidates redrawn after a NaN cost (pycma's ask_and_eval counts every
+ * evaluation, so `maxfevals` and the evaluation counter include the rejected ones). */
+int32_t ocd_cma_add_evals(ocd_cma *es, int64_t n);
 /* Any of the outputs may be NULL: mean [n], sigma, C [n, n], best_x [n], best_f, generations, evaluations,
  * max_axis = the largest sqrt-eigenvalue of C (the stopping rule sigma * max_axis < tolx). */
 int32_t ocd_cma_state(const ocd_cma *es, double *mean, double *sigma, double *C, double *best_x, double *best_f,
@@ -65,9 +69,12 @@ int32_t ocd_fitness_from_returns(const float *returns, int64_t P, int64_t N, int
  * every generation's best / median cost, ...): cma.evolution_strategy.fmin2's default options around mpc_ord.py:41,
  * restated (pycma is absent: parity unpinned; reward_design/cmaes.py:_Termination is the same logic in Python, used
  * by the numpy twin -- the tests compare the two).  opts and flags in the order
- *   maxiter, maxfevals, tolfun, tolfunhist, tolx, tolfacupx, tolconditioncov, tolupsigma, tolstagnation, tolflatfitness;
+ *   maxiter, maxfevals, tolfun, tolfunhist, tolx, tolfacupx, tolconditioncov, tolupsigma, tolstagnation, tolflatfitness,
+ *   noeffectaxis, noeffectcoord (pycma has no option value for the last two: opts[10], opts[11] are ignored);
+ * tolstagnation compares the newest l generations' best / median costs with the l just before them (pycma:
+ * histbest[:l] vs histbest[l:2l], newest first);
  * flags[i] = 1 where condition i holds; returns how many hold (0 = go on), -1 on bad arguments. */
-int32_t ocd_cma_stop(ocd_cma *es, const double opts[10], int32_t flags[10]);
+int32_t ocd_cma_stop(ocd_cma *es, const double opts[OCD_CMA_N_STOP], int32_t flags[OCD_CMA_N_STOP]);
 
 /* The episode launch and the stream wait the native generation loop calls -- function pointers, so that this library
  * stays free of HIP: ocd_rollout_episodes and ocd_stream_synchronize of include/ocd.h. */
@@ -88,7 +95,7 @@ typedef struct ocd_cma_run_args {
     int32_t normalise_variant;    /* ocd_normalise_weights: the dot order that reproduces numpy here */
     int32_t reserved;
     int64_t max_generations;      /* at most this many generations in this call */
-    double stop_opts[10];         /* ocd_cma_stop */
+    double stop_opts[OCD_CMA_N_STOP]; /* ocd_cma_stop */
     double *X;                    /* [lambda, n] the population (also the one a pending-NaN generation is left in) */
     double *cost;                 /* [lambda] its costs */
     double *hist_w;               /* [max_generations, lambda, n] rows normalised once (history entries), or NULL */
@@ -102,7 +109,7 @@ typedef struct ocd_cma_run_args {
  * Returns when a termination condition holds (stop_flags), after max_generations, or -- *pending_nan = 1 -- with a
  * generation evaluated but NOT told because a cost is NaN: the caller redraws those candidates as pycma does
  * (ocd_cma_resample), tells, and calls again.  *generations_done = generations told in this call. */
-int32_t ocd_cma_run(ocd_cma *es, const ocd_cma_run_args *a, int64_t *generations_done, int32_t stop_flags[10],
+int32_t ocd_cma_run(ocd_cma *es, const ocd_cma_run_args *a, int64_t *generations_done, int32_t stop_flags[OCD_CMA_N_STOP],
                     int32_t *pending_nan);
 
 /* K fitness evaluations of one fixed population back to back -- launch (a->rollout on the P rows of a->w_pinned, taken

@@ -235,6 +235,8 @@ mpc_chunk_kernel(const KernelParams p)
         // a degenerate width (ocd_device.h: bump_widths_degenerate) sends every pass of this control step to the evaluation of
         // every feature: through `beyond` in the straight-line builds, as the "no_feature_skips" knob does in the others
         widths_beyond |= widths_degenerate;
+        // x_hi = 0 (descriptor outside LaneGradConst's conditions): no shortened division on any lane (see ocd_kernels.hip)
+        if constexpr (lane_feats) widths_beyond |= (lgc.x_hi > 0.0f) ? 0ull : ~0ull;
         const bool full_step = p.no_skips || widths_degenerate != 0ull;
 
         // ---- control initialisation of this segment (naive_planner.py:107-116) ----

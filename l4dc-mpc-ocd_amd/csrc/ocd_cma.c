@@ -406,13 +406,14 @@ static double median_of(ocd_cma *es, const double *v, int64_t n)
 
 /* pycma's termination rules (reward_design/cmaes.py: _Termination.stop is the same logic in Python, used by the numpy
  * twin; tests compare the two).  opts / flags in the order: maxiter, maxfevals, tolfun, tolfunhist, tolx, tolfacupx,
- * tolconditioncov, tolupsigma, tolstagnation, tolflatfitness.  flags[i] = 1 where the condition holds; returns how many. */
-int32_t ocd_cma_stop(ocd_cma *es, const double opts[10], int32_t flags[10])
+ * tolconditioncov, tolupsigma, tolstagnation, tolflatfitness, noeffectaxis, noeffectcoord (the last two have no option
+ * value).  flags[i] = 1 where the condition holds; returns how many. */
+int32_t ocd_cma_stop(ocd_cma *es, const double opts[OCD_CMA_N_STOP], int32_t flags[OCD_CMA_N_STOP])
 {
     if (!es || !opts || !flags) return -1;
     const int n = es->n;
     int count = 0;
-    for (int i = 0; i < 10; ++i) flags[i] = 0;
+    for (int i = 0; i < OCD_CMA_N_STOP; ++i) flags[i] = 0;
     if ((double)es->gen >= opts[0]) flags[0] = 1;
     if ((double)es->counteval >= opts[1]) flags[1] = 1;
     if (es->gen > 0) {
@@ -440,14 +441,49 @@ int32_t ocd_cma_stop(ocd_cma *es, const double opts[10], int32_t flags[10])
             const double a = opts[8] / 5.0 / 2.0, b = (double)nb / 10.0;
             const int64_t ell = (int64_t)(a > b ? a : b);
             if (2 * ell < nb && ell > 0) {
-                const double m_new = median_of(es, es->histmedian + (nb - ell), ell), m_old = median_of(es, es->histmedian, ell);
-                const double b_new = median_of(es, es->histbest + (nb - ell), ell), b_old = median_of(es, es->histbest, ell);
+                /* the newest ell generations against the ell JUST BEFORE them (pycma keeps its lists newest first and
+                 * compares histbest[:l] with histbest[l:2l]) -- not against the start of the run, where costs are worst */
+                const double m_new = median_of(es, es->histmedian + (nb - ell), ell);
+                const double m_old = median_of(es, es->histmedian + (nb - 2 * ell), ell);
+                const double b_new = median_of(es, es->histbest + (nb - ell), ell);
+                const double b_old = median_of(es, es->histbest + (nb - 2 * ell), ell);
                 if (m_new >= m_old && b_new >= b_old) flags[8] = 1;
             }
         }
+        /* noeffectaxis: a step of 0.1 sigma along principal axis (generation mod n) -- axes in ascending order of
+         * their length, as numpy's eigh returns them to the numpy twin and to pycma -- no longer changes the mean in
+         * any coordinate; noeffectcoord: a step of 0.2 sigma sqrt(C_jj) no longer changes coordinate j.  pycma has
+         * no option value for either (always on). */
+        {
+            const int want = (int)(es->gen % n);
+            int k = 0;
+            for (int c = 0; c < n; ++c) {                 /* the axis with exactly `want` shorter (or equal, earlier) axes */
+                int rank = 0;
+                for (int j = 0; j < n; ++j) rank += (es->D[j] < es->D[c]) || (es->D[j] == es->D[c] && j < c);
+                if (rank == want) { k = c; break; }
+            }
+            int same = 0, coord = 0;
+            for (int j = 0; j < n; ++j) {
+                volatile double moved = es->mean[j] + 0.1 * es->sigma * es->D[k] * es->B[j * n + k];
+                same += (es->mean[j] == moved);
+                volatile double moved_c = es->mean[j] + 0.2 * es->sigma * sqrt(es->C[j * n + j]);
+                coord |= (es->mean[j] == moved_c);
+            }
+            if (same == n) flags[10] = 1;
+            if (coord) flags[11] = 1;
+        }
     }
-    for (int i = 0; i < 10; ++i) count += flags[i];
+    for (int i = 0; i < OCD_CMA_N_STOP; ++i) count += flags[i];
     return count;
+}
+
+/* Evaluations made outside tell(): the candidates redrawn after a NaN cost (pycma's ask_and_eval counts every
+ * evaluation, the rejected ones included, so maxfevals and the hsig correction see them). */
+int32_t ocd_cma_add_evals(ocd_cma *es, int64_t n)
+{
+    if (!es || n < 0) return -1;
+    es->counteval += n;
+    return 0;
 }
 
 int32_t ocd_cma_state(const ocd_cma *es, double *mean, double *sigma, double *C, double *best_x, double *best_f,
@@ -554,7 +590,7 @@ static void row_normalise_once(const double *x, int n, int variant, double *out)
     for (int i = 0; i < n; ++i) out[i] = x[i] / nrm;
 }
 
-int32_t ocd_cma_run(ocd_cma *es, const ocd_cma_run_args *a, int64_t *generations_done, int32_t stop_flags[10],
+int32_t ocd_cma_run(ocd_cma *es, const ocd_cma_run_args *a, int64_t *generations_done, int32_t stop_flags[OCD_CMA_N_STOP],
                     int32_t *pending_nan)
 {
     if (!es || !a || !generations_done || !stop_flags || !pending_nan) return -1;
@@ -564,7 +600,7 @@ int32_t ocd_cma_run(ocd_cma *es, const ocd_cma_run_args *a, int64_t *generations
     const int64_t E = (int64_t)lam * a->N * a->S;
     *generations_done = 0;
     *pending_nan = 0;
-    for (int i = 0; i < 10; ++i) stop_flags[i] = 0;
+    for (int i = 0; i < OCD_CMA_N_STOP; ++i) stop_flags[i] = 0;
     for (int64_t g = 0; g < a->max_generations; ++g) {
         double *sg = a->seconds ? a->seconds + 8 * g : NULL;
         const double t0 = now_s();

@@ -226,7 +226,7 @@ mpc_kernel(const KernelParams p)
     const int T = p.T;
     const PkConsts pkc = pk_consts();         // constants of the packed exp (ocd_devmath.h), pinned in registers
     ScConsts scc;                             // coefficient pairs of the two-wide sin / cos polynomials: V_ROW latency
-    if constexpr (LAT && V == V_ROW) scc = sc_consts();   //   builds only (V_SEG runs the scalar chains, see ocd_devmath.h)
+    if constexpr (LAT && !(V == V_SEG && asm_chains)) scc = sc_consts();   //   builds (V_SEG with its asm chains runs the scalar ones, see ocd_devmath.h; without them -- the -DOCD_NO_ASM_CHAINS ablation arm -- it calls sincos_pk too)
     OCD_STAMP_DECL
     float G_ret = 0.0f;
     const BumpGeom bg0 = {0.0f, 1.0f, 0.0f, 1.0f};
@@ -324,6 +324,10 @@ mpc_kernel(const KernelParams p)
         // a degenerate width (ocd_device.h: bump_widths_degenerate) sends every pass of this control step to the evaluation of
         // every feature: through `beyond` in the straight-line builds, through the knob mask in the others
         widths_beyond |= widths_degenerate;
+        // a descriptor outside LaneGradConst::x_hi's conditions (x_hi = 0) has no shortened division anywhere: the
+        // evaluations that run fence units on lanes outside the fence region (reward_fc / reward_fcc / reward_every)
+        // rely on those conditions too, so every live lane counts as beyond the guard, not only the fence lanes
+        if constexpr (lane_feats) widths_beyond |= (lgc.x_hi > 0.0f) ? 0ull : ~0ull;
         const unsigned long long force_full_step = force_full | widths_degenerate;
 
         // ---- this lane's control initialisation (naive_planner.py:107-116) ----

@@ -44,6 +44,9 @@ class _Termination:
         tolupsigma       1e20    sigma / sigma0 above tolupsigma * the longest axis of C ("creeping")
         tolstagnation    100 + 100 * N ** 1.5 / popsize   generations without progress of the median / best costs
         tolflatfitness   1       generations in a row whose best and median cost coincide
+        noeffectaxis     -       0.1 sigma along principal axis (generation mod N, axes by ascending length) no longer
+                                 changes the mean in any coordinate (no option value in pycma: always on)
+        noeffectcoord    -       0.2 sigma sqrt(C_jj) no longer changes coordinate j of the mean (always on)
     The "recent best costs" are those of the last 10 + 30 N / popsize generations, as in pycma.  stop() returns
     pycma's dict of the satisfied conditions ({} = go on), e.g. {'tolx': 1e-11}."""
 
@@ -111,10 +114,16 @@ class _Termination:
             out["tolflatfitness"] = o["tolflatfitness"]
         nb = len(self._histbest)
         if st["gen"] > self.n * (5 + 100 / self.lam) and nb > 100:
-            ell = int(max(o["tolstagnation"] / 5. / 2, nb / 10))        # the newest ell generations against the oldest
-            if 2 * ell < nb and (np.median(self._histmedian[-ell:]) >= np.median(self._histmedian[:ell])
-                                 and np.median(self._histbest[-ell:]) >= np.median(self._histbest[:ell])):
+            # the newest ell generations against the ell just before them: pycma keeps its lists newest first and
+            # compares histbest[:l] with histbest[l:2l] (not with the start of the run, where the costs are worst)
+            ell = int(max(o["tolstagnation"] / 5. / 2, nb / 10))
+            if 2 * ell < nb and (np.median(self._histmedian[-ell:]) >= np.median(self._histmedian[-2 * ell:-ell])
+                                 and np.median(self._histbest[-ell:]) >= np.median(self._histbest[-2 * ell:-ell])):
                 out["tolstagnation"] = o["tolstagnation"]
+        if st.get("noeffectaxis"):
+            out["noeffectaxis"] = None
+        if st.get("noeffectcoord"):
+            out["noeffectcoord"] = None
         return out
 
 
@@ -184,6 +193,10 @@ class CMAES(_Termination):
             self._X[k] = self.mean + self.sigma * self._y[k]
         return self._X[rows]
 
+    def add_evals(self, n):
+        """Evaluations made outside tell(): candidates redrawn after a NaN cost (pycma's ask_and_eval counts them)."""
+        self.counteval += int(n)
+
     def tell(self, X, fitness):
         """Returns the number of non-finite costs (they rank last: np.argsort puts NaN after +inf)."""
         fitness = np.asarray(fitness, dtype=np.float64)
@@ -245,7 +258,10 @@ class CMAES(_Termination):
 
     def _stop_state(self):
         d = np.sqrt(np.diag(self.C))
-        return dict(sigma=self.sigma, max_axis=float(np.max(self.Dg)), min_axis=float(np.min(self.Dg)), gen=self.gen,
+        i = self.gen % self.n                                       # eigh: axes in ascending order of their length
+        axis = bool(np.all(self.mean == self.mean + 0.1 * self.sigma * self.Dg[i] * self.B[:, i]))
+        coord = bool(np.any(self.mean == self.mean + 0.2 * self.sigma * d))
+        return dict(noeffectaxis=axis, noeffectcoord=coord, sigma=self.sigma, max_axis=float(np.max(self.Dg)), min_axis=float(np.min(self.Dg)), gen=self.gen,
                     counteval=self.counteval, sigma_max_std=float(self.sigma * d.max()),
                     sigma_max_pc=float(self.sigma * np.abs(self.pc).max()))
 
@@ -256,7 +272,8 @@ _D = C.POINTER(C.c_double)
 
 # the order of opts / flags of ocd_cma_stop (include/ocd_cma.h)
 STOP_NAMES = ("maxiter", "maxfevals", "tolfun", "tolfunhist", "tolx", "tolfacupx", "tolconditioncov", "tolupsigma",
-              "tolstagnation", "tolflatfitness")
+              "tolstagnation", "tolflatfitness", "noeffectaxis", "noeffectcoord")
+N_STOP = len(STOP_NAMES)                                            # OCD_CMA_N_STOP
 
 
 class RunArgs(C.Structure):
@@ -264,7 +281,7 @@ class RunArgs(C.Structure):
     _fields_ = [("scn", C.c_void_p), ("init_dev", C.c_void_p), ("N", C.c_int64), ("S", C.c_int64),
                 ("w_pinned", C.c_void_p), ("ret_pinned", C.c_void_p), ("stream", C.c_void_p),
                 ("rollout", C.c_void_p), ("sync", C.c_void_p), ("normalise_variant", C.c_int32), ("reserved", C.c_int32),
-                ("max_generations", C.c_int64), ("stop_opts", C.c_double * 10), ("X", C.c_void_p), ("cost", C.c_void_p),
+                ("max_generations", C.c_int64), ("stop_opts", C.c_double * 12), ("X", C.c_void_p), ("cost", C.c_void_p),
                 ("hist_w", C.c_void_p), ("hist_cost", C.c_void_p), ("seconds", C.c_void_p), ("nonfinite", C.c_void_p)]
 
 
@@ -279,17 +296,35 @@ def load_cma_library():
     srcs = [os.path.join(os.path.dirname(path), "ocd_cma.c"), os.path.join(root, "include", "ocd_cma.h")]
     stale = (not os.path.exists(path)) or any(
         os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(path) for f in srcs)
+    make_error = ""
     if stale:                                                       # plain gcc, no GPU involved; a no-op when current
+        # every rank of a torchrun job imports this: ONE of them builds (exclusive lock on a file beside the target),
+        # the others wait for the lock and find the target current; the Makefile writes a temporary and renames it
+        import fcntl
         import subprocess
-        r = subprocess.run(["make", "-C", os.path.dirname(path), "libocd_cma.so"], capture_output=True, text=True)
-        if r.returncode != 0 and not os.path.exists(path):
-            raise FileNotFoundError(f"{path} is missing and could not be built:\n{r.stderr[-1500:]}")
+        try:
+            lock = open(os.path.join(os.path.dirname(path), ".libocd_cma.lock"), "w")
+        except OSError:
+            lock = None                                             # read-only tree: nothing to build into either
+        try:
+            if lock is not None:
+                fcntl.flock(lock, fcntl.LOCK_EX)
+            r = subprocess.run(["make", "-C", os.path.dirname(path), "libocd_cma.so"], capture_output=True, text=True)
+            if r.returncode != 0:
+                make_error = r.stderr[-1500:]
+                if not os.path.exists(path):
+                    raise FileNotFoundError(f"{path} is missing and could not be built:\n{make_error}")
+        finally:
+            if lock is not None:
+                fcntl.flock(lock, fcntl.LOCK_UN)
+                lock.close()
     lib = C.CDLL(path)
     want = _header_abi_version(srcs[1])
     have = lib.ocd_cma_abi_version() if hasattr(lib, "ocd_cma_abi_version") else 1
     if want is not None and have != want:
         raise RuntimeError(f"{path} was built for ocd_cma.h ABI {have}, the header says {want}: run `make -C "
-                           f"{os.path.dirname(path)}` (a stale library would silently mismatch the ctypes signatures)")
+                           f"{os.path.dirname(path)}` (a stale library would silently mismatch the ctypes signatures)"
+                           + (f"; the rebuild attempted just now failed:\n{make_error}" if make_error else ""))
     lib.ocd_cma_create.restype = C.c_int32
     lib.ocd_cma_create.argtypes = [C.c_int32, _D, C.c_double, C.c_int32, C.c_uint32, C.POINTER(C.c_void_p)]
     lib.ocd_cma_destroy.restype = None
@@ -304,6 +339,8 @@ def load_cma_library():
     lib.ocd_cma_tell.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ocd_cma_resample.restype = C.c_int32
     lib.ocd_cma_resample.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    lib.ocd_cma_add_evals.restype = C.c_int32
+    lib.ocd_cma_add_evals.argtypes = [C.c_void_p, C.c_int64]
     lib.ocd_cma_stop_state.restype = C.c_int32
     lib.ocd_cma_stop_state.argtypes = [C.c_void_p, C.c_void_p]
     lib.ocd_cma_abi_version.restype = C.c_int32
@@ -363,8 +400,8 @@ class NativeCMAES(_Termination):
         self._f_ptr = self._f.ctypes.data
         self._ss = np.empty(13, dtype=np.float64)
         self._ss_ptr = self._ss.ctypes.data
-        self._opts_c = np.empty(10, dtype=np.float64)
-        self._flags_c = np.zeros(10, dtype=np.int32)
+        self._opts_c = np.zeros(N_STOP, dtype=np.float64)
+        self._flags_c = np.zeros(N_STOP, dtype=np.int32)
         self._init_termination(sigma0)
 
     def __del__(self):
@@ -387,6 +424,11 @@ class NativeCMAES(_Termination):
             if self.lib.ocd_cma_resample(self._h, int(k), self._X_ptr) != 0:
                 raise IndexError(f"ocd_cma_resample: no slot {int(k)} in a population of {self.lam}")
         return self._X[rows]
+
+    def add_evals(self, n):
+        """Evaluations made outside tell(): candidates redrawn after a NaN cost (pycma's ask_and_eval counts them)."""
+        if self.lib.ocd_cma_add_evals(self._h, int(n)) != 0:
+            raise ValueError("ocd_cma_add_evals: bad arguments")
 
     def tell(self, X, fitness):
         """The update from the population last asked for.  X must BE that population (the array ask() returned, rows
@@ -416,11 +458,11 @@ class NativeCMAES(_Termination):
         numpy twin runs the same rules in Python: _Termination.stop).  {} = go on."""
         o = self._stop_opts(dict(tolfun=tolfun, tolx=tolx, maxiter=maxiter, **overrides))
         for i, k in enumerate(STOP_NAMES):
-            self._opts_c[i] = o[k]
+            self._opts_c[i] = o.get(k, 0.0)
         n = self.lib.ocd_cma_stop(self._h, self._opts_c.ctypes.data, self._flags_c.ctypes.data)
         if n < 0:
             raise RuntimeError("ocd_cma_stop failed")
-        return {k: o[k] for i, k in enumerate(STOP_NAMES) if self._flags_c[i]} if n else {}
+        return {k: o.get(k) for i, k in enumerate(STOP_NAMES) if self._flags_c[i]} if n else {}
 
     def run(self, args: "RunArgs", overrides):
         """ocd_cma_run: generations in native code until a termination rule holds, `args.max_generations` are done, or
@@ -428,7 +470,7 @@ class NativeCMAES(_Termination):
         pending_nan)."""
         o = self._stop_opts(overrides)
         for i, k in enumerate(STOP_NAMES):
-            args.stop_opts[i] = o[k]
+            args.stop_opts[i] = o.get(k, 0.0)
         args.X, args.cost = self._X_ptr, self._f_ptr
         done, pending = C.c_int64(0), C.c_int32(0)
         st = self.lib.ocd_cma_run(self._h, C.byref(args), C.byref(done), self._flags_c.ctypes.data, C.byref(pending))
@@ -436,7 +478,7 @@ class NativeCMAES(_Termination):
             raise RuntimeError(f"ocd_cma_run -> {st}")
         self.lib.ocd_cma_stop_state(self._h, self._ss_ptr)
         self.last_nonfinite, self.nonfinite_total = int(self._ss[8]), int(self._ss[9])
-        why = {k: o[k] for i, k in enumerate(STOP_NAMES) if self._flags_c[i]}
+        why = {k: o.get(k) for i, k in enumerate(STOP_NAMES) if self._flags_c[i]}
         return int(done.value), why, bool(pending.value)
 
     def finish_tell(self):                                         # (the numpy twin defers work; nothing to do here)

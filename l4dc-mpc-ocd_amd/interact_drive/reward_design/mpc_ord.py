@@ -318,8 +318,9 @@ class MPC_ORD:
         self.should_save_history = True
         self.eval_weights(self.designer_weights)                       # "Iteration 0" baseline
         es = NativeCMAES(list(self.designer_weights), sigma0, popsize=popsize, seed=seed)   # csrc/ocd_cma.c
-        self.generation_seconds = []
-        self.fitness_seconds = []
+        self.generation_seconds = []                               # per generation: ask ... termination test
+        self.generation_wall_seconds = []                          # the same plus the interpreter's bookkeeping (history rows,
+        self.fitness_seconds = []                                  #   counters): wall-clock of the loop / generations
         self.host_split = {}
         self.n_resampled = 0
         self.stop_reason = {}
@@ -345,6 +346,7 @@ class MPC_ORD:
                     why = es.stop(**overrides)
                     self._tick("stop", t3)
                     self.generation_seconds.append(time.perf_counter() - t0)     # ask ... termination test
+                    self.generation_wall_seconds.append(self.generation_seconds[-1])
                     if why:
                         self.stop_reason = why
                         break
@@ -371,7 +373,9 @@ class MPC_ORD:
             return False
         return hasattr(es, "run") and _native_normalise_variant(self.weight_dim) is not None
 
-    def _optimize_cmaes_native(self, es, overrides, chunk=64):
+    native_chunk = 64                                                # generations per ocd_cma_run call
+
+    def _optimize_cmaes_native(self, es, overrides, chunk=None):
         """The loop of optimize_cmaes through ocd_cma_run: ask, normalise into the pinned rows, launch, (next deviates
         and history rows while the GPU works,) wait, reduce, tell, termination test -- generation after generation
         without returning to the interpreter; Python only books the results every `chunk` generations and handles the
@@ -381,6 +385,7 @@ class MPC_ORD:
         from .cmaes import RunArgs
         from ...scenarios import _native_normalise_variant
         eng = self._eng_fixed
+        chunk = int(chunk or self.native_chunk)
         with torch.cuda.device(eng.device):
             init = self._init_key_array(self.init_car_states)
             P, N, S, D = es.lam, init.shape[0], self.num_samples, self.weight_dim
@@ -412,6 +417,7 @@ class MPC_ORD:
                         self.world.unlucky_car_idx = 2 if self.world.unlucky_car_idx == 1 else 1
 
             while True:
+                t_chunk = time.perf_counter()
                 done, why, pending = es.run(a, overrides)
                 book(0, done)
                 for g in range(done):
@@ -420,6 +426,8 @@ class MPC_ORD:
                     self.n_nonfinite.append(int(nonf[g]))
                     for k, name in enumerate(names):
                         self.host_split.setdefault(name, []).append(float(secs[g, 1 + k]))
+                if done:        # what the C timers do not see: this call's share of the interpreter (history, counters)
+                    self.generation_wall_seconds.extend([(time.perf_counter() - t_chunk) / done] * done)
                 if pending:                                        # generation `done` is evaluated, not told: redraw its NaN
                     t0 = time.perf_counter()
                     book(done, done + 1)
@@ -430,6 +438,7 @@ class MPC_ORD:
                     es.tell(es._X, f)
                     why = es.stop(**overrides)
                     self.generation_seconds.append(float(secs[done, 0]) + time.perf_counter() - t0)
+                    self.generation_wall_seconds.append(self.generation_seconds[-1])
                     self.fitness_seconds.append(self.generation_seconds[-1])
                 if why:
                     self.stop_reason = why
@@ -446,6 +455,7 @@ class MPC_ORD:
                 break
             Xr = es.resample(rows)
             self.n_resampled += int(rows.size)
+            es.add_evals(rows.size)                                # pycma counts the rejected evaluations too
             f[rows] = self.eval_population(Xr)
         return f
 

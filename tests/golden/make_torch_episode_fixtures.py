@@ -14,6 +14,8 @@ Cases (reference horizons: a float64 run is a meaningful target there, DESIGN.md
   finite_horizon_h6                                               H = 6 -> n_iter = 200 (mpc_ord.py:192), 2 x 4
   local_opt_h5_extra                                              extra_inits: 6 control initialisations, 2 x 4
   finite_horizon_h10, local_opt_h10, replanning_h10, merging_h10  H = 10 (BASELINE configs 2 / 3's horizon), 4 x 8
+  replanning_h15                                                  H = 15, T = 20, both samples (BASELINE config 4), 2 x 8 x 2
+  merging_h25                                                     H = 25 (BASELINE config 5), 2 x 4
 Candidates: the designer's weights (the "Iteration 0" evaluation, mpc_ord.py:39), the scenario's tuned weights
 (run_mpc_ord.py:25-42) where the reference has them, and designer + 0.05 * N(0, I) draws (run_mpc_ord.py:59).
 Inits: get_init_state(env_seed) of the scenario factories with env_seeds (seed * 1e6 + i) % 2**32
@@ -27,6 +29,19 @@ margin / sample_reward / designer_reward / cost / removed / planner_w32 / design
                     the fp64 one (an argmin between two initialisations decided in the last bits) no fp32
                     implementation can be expected to follow it.
   fp32_sample_reward [E]   torch's float32 returns (information).
+and, since round 5, a THIRD float64 run whose Python-float constants are the float32 numbers the reference's traced
+graph holds (torch_episode._Constants: "the reference's graph without rounding error" -- what a float64 build of a
+float32 implementation computes), so that float64 implementations can be compared far below 1e-4 at the horizons
+where the 1e-8 between fp32(0.1) and 0.1 is amplified past it:
+  c32_states / c32_past / c32_controls / c32_chosen / c32_sample_reward    that run (shapes as above)
+  c32_stable_steps [E] int   torch's OWN sensitivity: the same run with every ego init state multiplied by 1 + 1e-13
+                    follows it within 1e-8 (controls and states) for this many leading control steps; = T where the
+                    whole episode does.  A hundred plain-SGD steps amplify 1e-13 past 1e-3 on some plans at H >= 10:
+                    beyond that step no second float64 implementation can be expected to land on the same numbers.
+  c32_final_plans [E,T,K,H,2], c32_final_losses [E,T,K], c32_final_grad [E,T,K,H,2]   (H >= 10 cases) what
+                    generate_plan ended on for every control initialisation at every control step, with dR/du there:
+                    single objective + gradient evaluations at the run's own world states (c32_past) -- nothing
+                    iterated, comparable at 1e-9 on EVERY episode and step whatever the horizon.
 
 usage: python tests/golden/make_torch_episode_fixtures.py [case ...]      (deterministic; ~1 min per case)
 """
@@ -79,13 +94,16 @@ CASES = {
     "local_opt_h10": (lambda: te.local_opt(10), 4, 8),
     "replanning_h10": (lambda: te.replanning(10), 4, 8),
     "merging_h10": (lambda: te.merging(10), 4, 8),
+    # BASELINE configs 4 / 5's horizons (round 5): the witness at the depth those configs unroll naive_planner.py:33-77
+    "replanning_h15": (lambda: te.replanning(15), 2, 8),
+    "merging_h25": (lambda: te.merging(25), 2, 4),
 }
 
 
 # seeds of the designer + 0.05 N(0, I) candidate draws (explicit: adding a case must not move the others')
 CANDIDATE_SEEDS = {"finite_horizon_h5": 100, "finite_horizon_h6": 101, "local_opt_h5": 102, "local_opt_h5_extra": 103,
                    "merging_h5": 104, "replanning_h5": 105, "finite_horizon_h10": 100, "local_opt_h10": 104,
-                   "replanning_h10": 106, "merging_h10": 107}
+                   "replanning_h10": 106, "merging_h10": 107, "replanning_h15": 108, "merging_h25": 109}
 
 
 def make(case):
@@ -107,12 +125,26 @@ def make(case):
                extra_inits=np.int32(spec["extra_inits"]), eval_horizon=np.int32(spec["eval_horizon"]),
                num_samples=np.int32(spec["num_samples"]), scenario=np.array(spec["name"]))
     out.update(r64)
+    # float64 arithmetic on the reference's float32 constants, and torch's own verdict on how far it is determined
+    keep = spec["horizon"] >= 10
+    c32 = te.run(spec, inits, list(cands), dtype=torch.float64, constants="float32", keep_plans=keep)
+    c32n = te.run(spec, inits, list(cands), dtype=torch.float64, constants="float32", nudge=1e-13)
+    T = spec["eval_horizon"]
+    dstep = np.maximum(np.abs(c32n["controls"] - c32["controls"]).max(axis=2),
+                       np.abs(c32n["states"][:, 1:] - c32["states"][:, 1:]).reshape(E, T, -1).max(axis=2))
+    bad = dstep > 1e-8
+    stable_steps = np.where(bad.any(axis=1), bad.argmax(axis=1), T).astype(np.int32)
+    for k in ("states", "past", "controls", "chosen", "sample_reward", "final_plans", "final_losses", "final_grad"):
+        if k in c32:
+            out["c32_" + k] = c32[k]
+    out["c32_stable_steps"] = stable_steps
     path = os.path.join(HERE, f"torch_episode_{case}.npz")
     np.savez_compressed(path, **out)
     print(f"{os.path.basename(path)}: {E} episodes, fp32-stable {int(stable.sum())}/{E}, returns "
           f"{r64['sample_reward'].min():.4f} .. {r64['sample_reward'].max():.4f}, costs {np.round(r64['cost'], 4)}, "
           f"chosen-init histogram {np.bincount(r64['chosen'].ravel()).tolist()}, removed {np.bincount(r64['removed']).tolist()}, "
-          f"{time.time() - t0:.0f} s", flush=True)
+          f"float64 run determined (1e-13 nudge stays below 1e-8) on {int((stable_steps == T).sum())}/{E} whole episodes, "
+          f"{int(stable_steps.sum())}/{E * T} leading steps, {time.time() - t0:.0f} s", flush=True)
 
 
 def main():

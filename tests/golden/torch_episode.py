@@ -169,16 +169,34 @@ def planner_weights_of(candidate):
 # ----------------------------------------------------------------------------------------------------------------
 # arithmetic (batched over leading dimensions)
 # ----------------------------------------------------------------------------------------------------------------
+class _Constants:
+    """How a Python-float constant of the reference meets a tensor.  TensorFlow converts it to the tensor's dtype,
+    float32 -- `dt`, `dt ** 2` (squared in Python first), `friction`, 0.08, `threshold - width` ... are float32
+    numbers in the traced graph.  A float32 torch run does the same conversion by itself.  A float64 run has two
+    meanings: `exact` (the default: the Python doubles as typed -- the mathematically intended expressions), and
+    `float32` (K.round32 = True: the reference's OWN constants, the float32 roundings, carried in double arithmetic:
+    "the reference's graph without rounding error").  The second is what a float64 build of any float32
+    implementation computes, so two such builds can be compared far below 1e-4 at horizons where the 1e-8 between
+    fp32(0.1) and 0.1 is amplified past it (H >= 10)."""
+    round32 = False
+
+    def __call__(self, x):
+        return float(np.float32(x)) if self.round32 else x
+
+
+K = _Constants()
+
+
 def _f(x, shape):                                                       # math_utils.py:28-31
     pos = x > 0
     x_clipped = torch.where(pos, x, torch.zeros_like(x) + 0.01)
-    return torch.where(pos, torch.exp(-1 / (shape * x_clipped)), torch.zeros_like(x))
+    return torch.where(pos, torch.exp(-1 / (K(shape) * x_clipped)), torch.zeros_like(x))
 
 
 def _smooth_threshold(x, threshold, width, c=5.):                       # math_utils.py:85-95
     shape = c / width
-    x_diff = x - (threshold - width)
-    return _f(x_diff, shape) / (_f(x_diff, shape) + _f(width - x_diff, shape))
+    x_diff = x - K(threshold - width)
+    return _f(x_diff, shape) / (_f(x_diff, shape) + _f(K(width) - x_diff, shape))
 
 
 def _smooth_bump(x, start, end):                                        # math_utils.py:166-178
@@ -197,10 +215,10 @@ def _dynamics(s, acc, ang_vel, dt, friction):                           # simula
     acc = torch.where(acc >= -2 * four, acc, -2 * four)                 # tf.maximum(., -2*4.)
     ang_vel = torch.where(ang_vel <= four, ang_vel, four)
     ang_vel = torch.where(ang_vel >= -four, ang_vel, -four)
-    total_acc = acc - friction * v ** 2
-    distance_travelled = v * dt + 0.5 * total_acc * (dt ** 2)
+    total_acc = acc - K(friction) * v ** 2
+    distance_travelled = v * K(dt) + 0.5 * total_acc * K(dt ** 2)
     return torch.stack([x + torch.cos(angle) * distance_travelled, y + torch.sin(angle) * distance_travelled,
-                        v + total_acc * dt, angle + ang_vel * dt], dim=-1)
+                        v + total_acc * K(dt), angle + ang_vel * K(dt)], dim=-1)
 
 
 class _Sim:
@@ -211,6 +229,7 @@ class _Sim:
         self.target_speed = float(ts)
         self.speed_bound = float(4 * ts ** 2)                           # merging.py:59, float32 scalar arithmetic
         self.n_others = len(spec["others"])
+        self.keep_plans = None                                          # a list: (plans, losses, dR/du) per control step
 
     def features(self, ego, others):
         """ThreeLaneTestCar.features (merging.py:51-83); ego [..., 4], others [..., n_others, 4] -> [..., D]."""
@@ -221,7 +240,7 @@ class _Sim:
         bound = torch.full_like(sq, self.speed_bound)
         feats.append(torch.where(sq <= bound, sq, bound))
         for lane in sp["lanes"]:
-            r = (ego[..., 0] - lane.p[0]) * lane.n[0] + (ego[..., 1] - lane.p[1]) * lane.n[1]   # world.py:216-218
+            r = (ego[..., 0] - K(lane.p[0])) * K(lane.n[0]) + (ego[..., 1] - K(lane.p[1])) * K(lane.n[1])   # world.py:216-218
             d = r ** 2 * 10
             lane_dists.append(d)
             feats.append(d)
@@ -229,8 +248,8 @@ class _Sim:
         collision = []
         for j in range(self.n_others):                                  # the ego's own bump is computed and dropped
             o = others[..., j, :]
-            collision.append(_smooth_bump(ego[..., 0], o[..., 0] - 0.08, o[..., 0] + 0.08)
-                             * _smooth_bump(ego[..., 1], o[..., 1] - 0.15, o[..., 1] + 0.15))
+            collision.append(_smooth_bump(ego[..., 0], o[..., 0] - K(0.08), o[..., 0] + K(0.08))
+                             * _smooth_bump(ego[..., 1], o[..., 1] - K(0.15), o[..., 1] + K(0.15)))
         feats.append(torch.amax(torch.stack(collision, dim=0), dim=0))
         thr, x = 0.05 * sp["num_lanes"], ego[..., 0]
         feats.append((_smooth_threshold(x, thr, width=0.05) + _smooth_threshold(-x, thr, width=0.05)) * torch.abs(x))
@@ -245,11 +264,11 @@ class _Sim:
             v, angle = others[..., 2], others[..., 3]
             if other_controls is not None:
                 acc, ang_vel = other_controls[:, t, 0], other_controls[:, t, 1]
-                update = torch.stack([torch.cos(angle) * (v * dt + 0.5 * acc * dt ** 2),
-                                      torch.sin(angle) * (v * dt + 0.5 * acc * dt ** 2),
-                                      acc * dt + torch.zeros_like(v), ang_vel * dt + torch.zeros_like(v)], dim=-1)
+                update = torch.stack([torch.cos(angle) * (v * K(dt) + 0.5 * acc * K(dt ** 2)),
+                                      torch.sin(angle) * (v * K(dt) + 0.5 * acc * K(dt ** 2)),
+                                      acc * K(dt) + torch.zeros_like(v), ang_vel * K(dt) + torch.zeros_like(v)], dim=-1)
             else:
-                update = torch.stack([torch.cos(angle) * v * dt, torch.sin(angle) * v * dt,
+                update = torch.stack([torch.cos(angle) * v * K(dt), torch.sin(angle) * v * K(dt),
                                       torch.zeros_like(v), torch.zeros_like(v)], dim=-1)
             others = others + update
             r = r + torch.sum(weights * self.features(ego, others), dim=-1)
@@ -260,11 +279,11 @@ class _Sim:
         Returns plans [E, K, H, 2], losses [E, K], best [E]."""
         sp, dtype = self.spec, self.dtype
         E, H = ego.shape[0], sp["horizon"]
-        cols = [(torch.zeros(E, dtype=dtype), 0.0), (torch.zeros(E, dtype=dtype), -5 * 0.13),
-                (torch.zeros(E, dtype=dtype), 5 * 0.13)]
+        cols = [(torch.zeros(E, dtype=dtype), 0.0), (torch.zeros(E, dtype=dtype), K(-5 * 0.13)),
+                (torch.zeros(E, dtype=dtype), K(5 * 0.13))]
         if sp["extra_inits"]:
-            coast = sp["friction"] * ego[:, 2] ** 2                     # self.car.friction * self.car.state[2] ** 2
-            cols += [(coast, 0.0), (coast, -5 * 0.13), (coast, 5 * 0.13)]
+            coast = K(sp["friction"]) * ego[:, 2] ** 2                  # self.car.friction * self.car.state[2] ** 2
+            cols += [(coast, 0.0), (coast, K(-5 * 0.13)), (coast, K(5 * 0.13))]
         u = torch.stack([torch.stack([a, torch.full((E,), w, dtype=dtype)], dim=-1) for a, w in cols], dim=1)
         u = u[:, :, None, :].repeat(1, 1, H, 1)                         # [E, K, H, 2]
         e1, o1, w1 = ego[:, None, :], others[:, None, :, :], weights[:, None, :]
@@ -273,9 +292,13 @@ class _Sim:
             u = u.detach().requires_grad_(True)
             loss = -self.mpc_reward(e1, o1, u, other_controls, w1)
             (g,) = torch.autograd.grad(loss.sum(), u)
-            u = u - lr * g                                              # keras SGD, no momentum
+            u = u - K(lr) * g                                           # keras SGD, no momentum
         u = u.detach()
         losses = -self.mpc_reward(e1, o1, u, other_controls, w1)
+        if self.keep_plans is not None:                                 # the objective's gradient at the END points too
+            ug = u.clone().requires_grad_(True)
+            (g,) = torch.autograd.grad(self.mpc_reward(e1, o1, ug, other_controls, w1).sum(), ug)
+            self.keep_plans.append((u.numpy().copy(), losses.numpy().copy(), g.numpy().copy()))
         best = torch.zeros(E, dtype=torch.long)                         # losses.index(min(losses)): first index wins
         cur = losses[:, 0]
         for k in range(1, losses.shape[1]):
@@ -300,8 +323,17 @@ class _WorldBookkeeping:
         return self.unlucky_car_idx if self.replanning else 0
 
 
-def run(spec, init_states, candidates, dtype=torch.float64):
-    """Every episode MPC_ORD would run for `candidates` (list of weight vectors as pycma hands them over) on
+def run(spec, init_states, candidates, dtype=torch.float64, constants="exact", keep_plans=False, nudge=0.0):
+    """constants="float32": the reference's own (float32-rounded) constants in a float64 run, see _Constants.
+    keep_plans: also return, per control step, what generate_plan ended on for EVERY control initialisation --
+        final_plans [E, T, K, H, 2], final_losses [E, T, K] and final_grad [E, T, K, H, 2] = dR/du at those end points
+        (one objective + gradient evaluation per (world state, control sequence): nothing iterated, so two float64
+        implementations can be compared on them at any horizon).
+    nudge: multiply every ego init state by (1 + nudge) AFTER its float32 cast (1e-13: a millionth of float32's
+        resolution).  The generator uses it to let torch ITSELF say which episodes a float64 run determines: where a
+        hundred SGD steps amplify 1e-13 to 1e-3 no second implementation can be expected to land on the same numbers.
+
+    Every episode MPC_ORD would run for `candidates` (list of weight vectors as pycma hands them over) on
     `init_states` [N, 4], in the reference's order: eval_weights per candidate -> inits -> samples.
 
     Returns a dict of numpy arrays (E = P * N * S episodes, flat index (p * N + n) * S + s):
@@ -316,7 +348,18 @@ def run(spec, init_states, candidates, dtype=torch.float64):
       removed [E]             car index the world teleported away (0 = none)
       planner_w32 [P, D], designer_w32 [D]
     """
+    assert constants in ("exact", "float32")
+    K.round32 = constants == "float32"
+    try:
+        return _run(spec, init_states, candidates, dtype, keep_plans, nudge)
+    finally:
+        K.round32 = False
+
+
+def _run(spec, init_states, candidates, dtype, keep_plans=False, nudge=0.0):
     sim = _Sim(spec, dtype)
+    if keep_plans:
+        sim.keep_plans = []
     book = _WorldBookkeeping(spec)
     init_states = np.asarray(init_states, dtype=np.float64)
     P, N, S, T = len(candidates), len(init_states), spec["num_samples"], spec["eval_horizon"]
@@ -334,7 +377,7 @@ def run(spec, init_states, candidates, dtype=torch.float64):
                 w_rows.append(pw)
     E = P * N * S
     t = lambda a: torch.tensor(np.asarray(a, dtype=np.float64), dtype=dtype)  # noqa: E731
-    ego = t(np.stack(ego0))                                             # Car.reset: state = init_state
+    ego = t(np.stack(ego0)) * (1 + nudge)                               # Car.reset: state = init_state
     others = t(np.stack([np.asarray(o["init"]).astype(np.float32) for o in spec["others"]]))[None].repeat(E, 1, 1)
     weights = t(np.stack(w_rows))
     dw = t(designer_w)
@@ -397,7 +440,12 @@ def run(spec, init_states, candidates, dtype=torch.float64):
         for n in range(N):
             acc += designer_reward[p, n]
         total[p] = acc / S
-    return dict(states=torch.stack(states, dim=1).numpy(), past=torch.stack(past, dim=1).numpy(),
+    extra = {}
+    if keep_plans:
+        extra = dict(final_plans=np.stack([k[0] for k in sim.keep_plans], axis=1),
+                     final_losses=np.stack([k[1] for k in sim.keep_plans], axis=1),
+                     final_grad=np.stack([k[2] for k in sim.keep_plans], axis=1))
+    return dict(extra, states=torch.stack(states, dim=1).numpy(), past=torch.stack(past, dim=1).numpy(),
                 controls=torch.stack(controls, dim=1).numpy(), chosen=torch.stack(chosen, dim=1).numpy().astype(np.int32),
                 margin=torch.stack(margin, dim=1).numpy(), sample_reward=sr, designer_reward=designer_reward,
                 cost=-total, removed=np.asarray(removed, dtype=np.int32),

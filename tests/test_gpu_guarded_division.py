@@ -186,3 +186,40 @@ def test_descriptors_at_and_beyond_the_static_guards_bitwise(hip, oracle, name, 
     for k in ("all_losses", "all_plans", "plans", "best_loss"):
         assert same(out[k], ref[k]), (name, H, mode, EXTREME[case], k)
     assert np.array_equal(out["best_init"], ref["best_init"])
+
+
+@pytest.mark.parametrize("shape,width,lo", [(1e25, 0.05, 1e20), (1e-16, 1e15, 1e20), (1e25, 0.05, 0.1), (1e14, 0.05, 1e20)])
+@pytest.mark.parametrize("name,H,mode", [("replanning", 5, 0), ("replanning", 15, 4), ("merging", 10, 3), ("merging", 25, 4),
+                                         ("replanning", 5, 2)])
+def test_out_of_range_fence_with_overlapping_cars_away_from_the_fence(hip, oracle, name, H, mode, shape, width, lo):
+    """ADVICE round 4: when the descriptor fails LaneGradConst::x_hi's conditions (x_hi = 0) only FENCE lanes used to be
+    flagged as beyond the guard -- but the straight-line builds' reward_every / reward_fc run the fence units
+    (u = shape * 0.01, shape * (width + ...)) on EVERY lane.  Two scripted cars at rest on the same spot, the ego inside
+    both collision boxes (reward_every), no lane in the fence region (fence_lo = 1e20), fence_shape * 0.01 outside
+    recip_pair_guarded's [2^-46, 2^62]: the full divisions must run, bit for bit the oracle."""
+    from l4dc_mpc_ocd_amd.engine import Engine
+    base = scenarios.SCENARIOS[name](horizon=H)
+    d = abi.ScenarioDesc.from_buffer_copy(bytes(base.desc))
+    d.n_iter = 3
+    d.fence_lo, d.fence_width, d.fence_shape = lo, width, shape
+    scn = scenarios.Scenario(base.name + "_xhi0", d, base.init_dist, None)
+    dx = np.array([0.0, 0.01, -0.03, 0.05, 0.079, 0.2], dtype=np.float32)
+    dy = np.array([0.0, 0.05, -0.1, 0.149], dtype=np.float32)
+    X, Y = (a.ravel() for a in np.meshgrid(dx, dy))
+    B, C = X.size, d.n_cars
+    assert C == 3
+    ws = np.zeros((B, C, 4), dtype=np.float32)
+    ws[:, 0, 0], ws[:, 0, 1], ws[:, 0, 2], ws[:, 0, 3] = X, np.float32(-0.9) + Y, 0.3, np.pi / 2
+    ws[:, 1] = np.array([0.0, -0.9, 0.0, np.pi / 2], dtype=np.float32)        # two resting cars on the same spot:
+    ws[:, 2] = np.array([0.02, -0.88, 0.0, np.pi / 2], dtype=np.float32)      #   the ego is inside both collision boxes
+    w = scenarios.planner_weights_fp32(base.candidate_weights(1, seed=4)[0])
+    eng = Engine(scn, "cuda:0")
+    eng.set_option("scan_mode", mode)
+    if mode == 4:
+        eng.set_option("chunk_size", 5)
+    out = eng.plan_batch(ws, w, want_all=True)
+    assert eng.last_launch()["build_wavefronts_per_simd"] == 1                # the straight-line build is what is tested
+    ref = oracle.plan_batch(d, ws, w, other_plans=scn.other_plans())
+    for k in ("all_losses", "all_plans", "plans", "best_loss"):
+        assert same(out[k], ref[k]), (name, H, mode, k)
+    assert np.array_equal(out["best_init"], ref["best_init"])

@@ -301,6 +301,55 @@ def test_cmaes_termination_follows_pycma_defaults():
         assert "tolfacupx" in why, why
 
 
+def test_tolstagnation_compares_adjacent_windows():
+    """pycma's stagnation rule compares the newest l generations with the l just BEFORE them
+    (histbest[:l] vs histbest[l:2l], newest first), not with the start of the run.  A run that improves for a
+    hundred generations and then sits on a noisy plateau must stop on tolstagnation soon after the two windows
+    both lie on the plateau -- against the (worst) costs of the start it never would -- and both twins must stop in
+    the same generation."""
+    from l4dc_mpc_ocd_amd.interact_drive.reward_design.cmaes import NativeCMAES
+    quiet = dict(tolfacupx=np.inf, tolupsigma=np.inf, tolconditioncov=np.inf, tolx=0.0)
+    stopped = []
+    for cls in (CMAES, NativeCMAES):
+        es = cls([0.0] * 7, 0.1, seed=5)
+        rng = np.random.default_rng(17)                              # the costs do not depend on X: same for both twins
+        for g in range(1200):
+            X = es.ask()
+            es.tell(X, max(1.0, 100.0 - g) + 1e-3 * rng.random(9))
+            why = es.stop(**quiet)
+            if why:
+                break
+        assert set(why) == {"tolstagnation"}, why
+        # the rule needs gen > N (5 + 100 / popsize) = 112.8 and 2 l < len(history), l = max(305 / 10, len / 10);
+        # both windows reach the plateau (generation 99 on) once 2 l <= len - 99
+        assert 160 <= g <= 400, g
+        stopped.append(g)
+        # while the run still improves every generation the rule stays quiet
+        es = cls([0.0] * 7, 0.1, seed=5)
+        for g in range(400):
+            X = es.ask()
+            es.tell(X, 1000.0 - g + 1e-3 * rng.random(9))
+            assert "tolstagnation" not in es.stop(**quiet), g
+    assert stopped[0] == stopped[1], stopped
+
+
+def test_noeffect_rules_fire_when_a_step_no_longer_moves_the_mean():
+    """pycma's noeffectaxis / noeffectcoord: a mean of 1e6 with sigma 1e-12 cannot be moved by 0.2 sigma in any
+    coordinate; an ordinary search never reports either.  Same answers from both twins."""
+    from l4dc_mpc_ocd_amd.interact_drive.reward_design.cmaes import NativeCMAES
+    for cls in (CMAES, NativeCMAES):
+        es = cls([1e6] * 3, 1e-12, seed=4)
+        X = es.ask()
+        es.tell(X, np.arange(es.lam, dtype=np.float64))
+        why = es.stop()
+        assert "noeffectcoord" in why and "noeffectaxis" in why and why["noeffectaxis"] is None, why
+        es = cls([1.0] * 5, 0.3, seed=4)
+        for g in range(40):
+            X = es.ask()
+            es.tell(X, np.sum((X - 0.25) ** 2, axis=1))
+            assert not {"noeffectcoord", "noeffectaxis"} & set(es.stop()), g
+
+
 def test_a_stale_cma_library_is_refused(tmp_path, monkeypatch):
     """a libocd_cma.so built from an older header must not be bound silently."""
     from l4dc_mpc_ocd_amd.interact_drive.reward_design import cmaes
