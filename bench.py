@@ -27,6 +27,14 @@ step at N=1 as well.
 anything touches the GPU) unless it already runs under a launcher (WORLD_SIZE set); the world size
 must equal --gpus or the run fails.
 
+At N > 1 the line also carries `config4` and `config5`: BASELINE configs 4 / 5 AS STATED (replanning pop 128 x 64 inits x 2
+samples at H=15; merging pop 256 x 128 inits at H=25), the fixed population split into N candidate blocks (strong
+scaling), the RCCL all-gather of the returns inside every timed step, max-over-ranks wall-clock, every rank's kernel ms.
+Every block that names a BASELINE config carries `parity`: an UNTIMED check of this run's HIP results against the CPU
+oracle (the oracle as checker, outside every timed region) on a bounded sample of episodes spread over every rank's block
+-- returns, world trajectories and applied controls bit for bit, returns within 1e-4 relative, and the kept control
+initialisation of every control step (`argmin_flips`); counts are summed over the ranks.
+
 Prints ONE JSON line (rank 0).  `roofline` follows the contract's hbm/mfma vocabulary although the
 path is bound by fp32 VALU issue: the HBM fraction on algorithmic bytes is reported as
 it is (tiny), and `valu` gives the fp32-vector fraction and the measured VALU issue utilisation.
@@ -134,6 +142,61 @@ def cpu_baseline(scn, inits, w32, budget_s=16.0):
                       f"threads, {dt:.1f} s of CPU work (oracle/ocd_oracle.c)"}
 
 
+def _same_bits(a, b):
+    """Element-wise: equal, or both NaN."""
+    return (a == b) | (np.isnan(a) & np.isnan(b))
+
+
+def parity_sample(scn, eng, inits, w32, e0, e1, n_want, n_threads):
+    """Untimed parity of the HIP path against the CPU oracle (the checker) on episodes of [e0, e1): `n_want` episodes in
+    up to 8 contiguous chunks spread evenly over the range.  Returns counts (numpy int64 [6]):
+    episodes_checked, bitwise_equal (returns AND every world state AND every applied control of the episode),
+    within_1e-4_rel (returns), plan_steps_checked, argmin_flips (control steps at which ocd_plan_batch, run on the HIP
+    episode's own world state, keeps another control initialisation than the oracle's planner does), nonfinite_returns."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    orc = oracle_lib.load()
+    d = scn.desc
+    N, S, T = inits.shape[0], d.n_samples, d.episode_len
+    n_local = e1 - e0
+    n = int(min(n_local, n_want))
+    chunks = 8 if n >= 64 else 1
+    per = n // chunks
+    counts = np.zeros(6, dtype=np.int64)
+    if per < 1:
+        return counts
+    other = scn.other_plans()
+    for c in range(chunks):
+        b = e0 + (c * (n_local - per)) // max(chunks - 1, 1)
+        got = eng.rollout(inits, w32, ep_begin=b, ep_end=b + per, want_traj=True)
+        ref = orc.rollout(d, inits, w32, ep_begin=b, ep_end=b + per, want_traj=True, n_threads=n_threads)
+        same = _same_bits(got["returns"], ref["returns"]) \
+            & _same_bits(got["traj"], ref["traj"]).reshape(per, -1).all(axis=1) \
+            & _same_bits(got["ctrl"], ref["ctrl"]).reshape(per, -1).all(axis=1)
+        with np.errstate(invalid="ignore"):
+            close = np.abs(got["returns"].astype(np.float64) - ref["returns"]) <= 1e-4 * np.maximum(1e-2, np.abs(ref["returns"]))
+        close |= np.isnan(got["returns"]) & np.isnan(ref["returns"])
+        # the state each control step plans from: the state after the previous step, after the teleport if this is its step
+        ws = got["traj"][:, :T].copy()                                          # [per, T, C, 4]
+        if d.teleport_step > 0 and d.teleport_step <= T:
+            ep = np.arange(b, b + per)
+            k = (ep % d.teleport_period) if d.teleport_period > 0 else (ep % S)
+            car = np.array([d.teleport_car[i] for i in range(max(d.teleport_period, S))], dtype=np.int64)[k]
+            ws[np.arange(per), d.teleport_step - 1, car] = np.array(d.teleport_state[:], dtype=np.float32)
+        rows = np.repeat(w32[np.arange(b, b + per) // (N * S)], T, axis=0)
+        ws = ws.reshape(per * T, d.n_cars, 4)
+        finite = np.isfinite(ws).reshape(per * T, -1).all(axis=1)               # (a runaway episode plans from inf / NaN)
+        k_hip = eng.plan_batch(ws[finite], rows[finite])["best_init"]
+        k_ref = orc.plan_batch(d, ws[finite], rows[finite], other_plans=other, n_threads=n_threads)["best_init"]
+        counts += np.array([per, int(same.sum()), int(close.sum()), int(finite.sum()), int((k_hip != k_ref).sum()),
+                            int((~np.isfinite(got["returns"])).sum())], dtype=np.int64)
+    return counts
+
+
+PARITY_KEYS = ("episodes_checked", "bitwise_equal", "within_1e-4_rel", "plan_steps_checked", "argmin_flips",
+               "nonfinite_returns")
+
+
 def spawn_ranks(args):
     """--gpus N without a launcher: start N ranks as a torch.distributed.run child.  Nothing in this
     process has touched the GPU; it only waits for the child and passes its exit code on."""
@@ -184,6 +247,9 @@ def main():
     ap.add_argument("--emulate-rank", default="", metavar="R/W",
                     help="single GPU: run the block that rank R of a W-way strong split would run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the untimed oracle parity samples of the BASELINE blocks")
+    ap.add_argument("--parity-episodes", type=int, default=256,
+                    help="episodes of every BASELINE-config block checked against the CPU oracle, over all ranks")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the config-2 block, the config-4/5 share blocks and the CMA-ES generation timing")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -372,13 +438,41 @@ def main():
         coll = None
         if sharded:                                                # the generation's one collective by itself
             coll = time_all_gather(ret_dev, P, N, S)
-        return dt, kern_ms, fit, (cfg, scn, inits, w32, P, N, S, e1 - e0, launch, coll)
+        if sharded:                                                # every rank's kernel time, in rank order
+            got = [None] * dist.get_world_size()
+            dist.all_gather_object(got, float(kern_ms))
+            launch["kernel_ms_per_rank"] = got
+        return dt, kern_ms, fit, (cfg, scn, inits, w32, P, N, S, e1 - e0, launch, coll, eng, e0, sharded)
+
+    def parity_of(ctx):
+        """The `parity` object of a block (None with --no-parity): this rank checks its own slice, counts are summed
+        over the ranks when the block was sharded."""
+        if args.no_parity:
+            return None
+        scn, inits, w32, eng, e0, sharded = ctx[1], ctx[2], ctx[3], ctx[10], ctx[11], ctx[12]
+        ranks = dist.get_world_size() if sharded else 1
+        want = max(32, -(-args.parity_episodes // ranks))
+        threads = max(1, min(usable_cores(), int(os.environ.get("OCD_CPU_THREADS", "64"))) // ranks)
+        t0 = time.perf_counter()
+        counts = parity_sample(scn, eng, inits, w32, e0, e0 + ctx[7], want, threads)
+        if sharded:
+            tt = torch.as_tensor(counts, device=device if args.backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+            counts = tt.cpu().numpy()
+        out = {k: int(v) for k, v in zip(PARITY_KEYS, counts)}
+        out["against"] = ("oracle/ocd_oracle.c (CPU restatement, the checker), untimed: returns + every world state + every "
+                          "applied control bit for bit; argmin_flips = control steps whose kept control initialisation "
+                          "differs (ocd_plan_batch at the episode's own world states)")
+        out["ranks"] = ranks
+        out["seconds"] = time.perf_counter() - t0
+        return out
 
     def share_block(cfg_index, r, w, steps, warmup):
         """Rank r's block of a w-way strong split of BASELINE config cfg_index, on this GPU alone."""
         P = scenarios.BASELINE_CONFIGS[cfg_index]["pop"]
         dt_, k_, fit_, ctx_ = timed_generations(cfg_index, P, w, r, steps, warmup, collective=False)
         b = block(cfg_index, dt_, k_, ctx_, steps, per_gpu_only=True)
+        b["parity"] = parity_of(ctx_)
         b["emulated_rank"] = f"{r}/{w}"
         b["generation_cost_checksum"] = float(np.sum(fit_))
         if not args.no_cpu_baseline:                                # this rank's candidate block on the host's cores
@@ -398,16 +492,23 @@ def main():
         # exactly `gens` generations: the step-size rules that would end this run earlier are switched off (the cost
         # is invariant to the scale of the weights, so sigma drifts upwards: pycma's tolfacupx fires after ~38
         # generations at pop 64)
+        m.native_chunk = 16                                     # (the timed 32 generations = two whole native calls)
         m.optimize_cmaes(seed=1, sigma0=0.05, popsize=popsize, maxiter=gens,
                          termination={"tolfacupx": float("inf"), "tolupsigma": float("inf")})
-        gs = np.array(m.generation_seconds[-32:]) * 1e3
+        # wall-clock per generation INCLUDING the interpreter's bookkeeping between native calls (history rows,
+        # counters): ADVICE round 4 -- the C timers (ask ... termination test) alone are reported beside it
+        gs = np.array(m.generation_wall_seconds[-32:]) * 1e3
+        gs_native = np.array(m.generation_seconds[-32:]) * 1e3
         fs = np.array(m.fitness_seconds[-32:]) * 1e3            # eval_population alone (no ask / tell)
         med = float(np.median(gs))
         if reduce_over_ranks and world > 1:
             tt = torch.tensor([med], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             med = float(tt.item())
-        return {"cma_generation_ms": med, "fitness_ms": float(np.median(fs)),
+        return {"cma_generation_ms": med, "cma_generation_native_timers_ms": float(np.median(gs_native)),
+                "fitness_ms": float(np.median(fs)),
+                "sampler_parity": "unpinned: own CMA-ES (pycma is not installed; sampler and termination table restated "
+                                  "from its documentation), the fitness values it is fed are bit-exact",
                 "generations_run": int(len(m.generation_seconds)), "generations_timed": int(len(gs)),
                 "popsize": int(m.es.lam), "n_inits": cfg["n_inits"], "stop_reason": {k: (None if v is None else float(v)) for k, v in m.stop_reason.items()},
                 "n_nonfinite": int(sum(m.n_nonfinite)), "n_resampled": int(m.n_resampled),
@@ -418,7 +519,7 @@ def main():
                         "termination rules; own CMA-ES, pycma is not installed"}
 
     def block(cfg_index, dt, kern_ms, ctx, steps, per_gpu_only=False):
-        cfg, scn, inits, w32, P, N, S, n_local, launch, _coll = ctx
+        cfg, scn, inits, w32, P, N, S, n_local, launch, _coll = ctx[:10]
         kernel_name = ("ocd::mpc_chunk_kernel" if launch["scan_mode"] == 4 else "ocd::mpc_kernel") + \
             f" ({launch['mapping']}" + (f", {launch['chunk']} steps per lane" if launch["chunk"] else "") + \
             f", {launch['trajectories_per_wavefront']} trajectories per wavefront, {launch['workgroups']} workgroups x " \
@@ -459,7 +560,12 @@ def main():
                          "traffic_source": PMC_SOURCE if pmc else None,
                          "kernel": kernel_name, "kernel_ms": kern_ms, "launch": launch,
                          "algorithmic_bytes_per_episode": nbytes,
-                         "note": "path is fp32-VALU issue bound, not HBM bound (SURVEY.md 8d); see valu"},
+                         # what actually bounds the kernel: fp32 vector issue -- algorithmic flops per
+                         # launch / kernel_ms against the fp32 vector peak (the same numbers as `valu`)
+                         "binding": "valu", "binding_frac": ach_tf / VALU_PEAK_TFLOPS,
+                         "binding_achieved": ach_tf, "binding_peak": VALU_PEAK_TFLOPS, "binding_unit": "TFLOP/s",
+                         "note": "the contract's hbm figures are kept as measured; the path is fp32-VALU issue bound, "
+                                 "not HBM bound (SURVEY.md 8d): `binding` / `binding_frac` name the bound that binds"},
             "valu": valu,
         }
         if profiled:
@@ -484,9 +590,11 @@ def main():
             raise SystemExit(f"bench.py: population {P_total} < {world} ranks")
         dt, kern_ms, fit, ctx = timed_generations(args.config, P_total, world, rank, args.steps, args.warmup)
     coll = ctx[9]
+    head_parity = parity_of(ctx)
 
     # ---- extras: config 2 (small-batch latency) on rank 0, CMA-ES generation wall-clock on all ranks ----
     extra2 = None
+    strong_blocks = {}
     shares = {}
     reference_blocks = {}
     cma = None
@@ -494,12 +602,32 @@ def main():
         if rank == 0 and args.config != 2:
             dt2, k2, _, ctx2 = timed_generations(2, scenarios.BASELINE_CONFIGS[2]["pop"], 1, 0, args.steps, args.warmup)
             extra2 = block(2, dt2, k2, ctx2, args.steps)
+            extra2["parity"] = parity_of(ctx2)
             if world == 1 and not args.no_cpu_baseline:
                 extra2["cpu_baseline"] = cpu_baseline(ctx2[1], ctx2[2], ctx2[3], budget_s=2.0)
         if rank == 0 and world == 1 and not emulate:
             # what ONE of 8 GPUs runs of BASELINE configs 4 / 5 (strong split): the shapes the 8-GPU lines are made of
             n_sh = max(3, min(args.steps, 20))
             shares = {f"config{c}_share8": share_block(c, 0, 8, n_sh, 2) for c in (4, 5)}
+        if world > 1 and not emulate:
+            # BASELINE configs 4 / 5 as BASELINE.json states them: the fixed population split over the ranks (strong
+            # scaling; mpc_ord.py:128-137, run_mpc_ord.py:83-90), the all-gather of the returns inside every timed step
+            n_st = max(3, min(args.steps, 20))
+            for c in (4, 5):
+                if c == args.config and args.scaling == "strong":
+                    continue                                       # (it is the headline of this run already)
+                P_c = scenarios.BASELINE_CONFIGS[c]["pop"]
+                if P_c < world:
+                    continue
+                dt_c, k_c, fit_c, ctx_c = timed_generations(c, P_c, world, rank, n_st, 2)
+                par_c = parity_of(ctx_c)
+                if rank == 0:
+                    b = block(c, dt_c, k_c, ctx_c, n_st)
+                    b.update(scaling="strong", steps=n_st, warmup=2, parity=par_c, collective=dict(ctx_c[9], in_timed_step=True),
+                             generation_cost_checksum=float(np.sum(fit_c)),
+                             sharding=f"population {P_c} split into {world} candidate blocks, one all_gather of fp32 "
+                                      f"returns per generation inside the timed step, max-over-ranks wall-clock")
+                    strong_blocks[f"config{c}"] = b
         cfg = spec_of(args.config)
         cma_pop = cfg["pop"] * world if args.scaling == "weak" else cfg["pop"]
         cma = cma_generations(cfg, cma_pop, reduce_over_ranks=True)
@@ -518,7 +646,7 @@ def main():
                 reference_blocks[name] = b
 
     if rank == 0:
-        cfg, scn, inits, w32, P, N, S, n_local, _, _ = ctx
+        cfg, scn, inits, w32, P, N, S, n_local = ctx[:8]
         d = scn.desc
         hb = block(args.config, dt, kern_ms, ctx, args.steps, per_gpu_only=bool(emulate))
         out = {
@@ -544,6 +672,8 @@ def main():
             "valu": hb["valu"],
             "generation_cost_checksum": float(np.sum(fit)),
         }
+        if head_parity is not None:
+            out["parity"] = head_parity
         if cma:
             out["cma_generation_ms"] = cma["cma_generation_ms"]
             out["cma"] = cma
@@ -552,6 +682,7 @@ def main():
         if extra2:
             out["config2"] = extra2
         out.update(shares)
+        out.update(strong_blocks)
         out.update(reference_blocks)
         if world == 1 and not args.no_cpu_baseline and not emulate:
             out["cpu_baseline"] = cpu_baseline(scn, inits, w32)

@@ -71,3 +71,10 @@ def test_bench_json_line():
         assert rb["cpu_baseline"]["value"] > 0 and rb["cpu_baseline"]["kind"] == "port"
     for blk in (d["config2"], s4, s5):
         assert blk["cpu_baseline"]["value"] > 0 and blk["cpu_baseline"]["cores"] >= 1
+    # every block that names a BASELINE config carries an untimed parity object against the CPU oracle
+    for blk, n_min in ((d, 256), (d["config2"], 128), (s4, 256), (s5, 256)):
+        par = blk["parity"]
+        assert par["episodes_checked"] >= n_min and par["bitwise_equal"] == par["episodes_checked"] == par["within_1e-4_rel"]
+        assert par["argmin_flips"] == 0 and par["plan_steps_checked"] >= par["episodes_checked"] * 10 and par["ranks"] == 1
+    # the parsed roofline object names the bound that binds (fp32 vector issue) beside the contract's HBM figures
+    assert rf["binding"] == "valu" and abs(rf["binding_frac"] - d["valu"]["frac"]) < 1e-12 and 0.05 < rf["binding_frac"] < 1

@@ -68,3 +68,33 @@ def test_rccl_runs_in_a_one_rank_group():
     assert forced["roofline"]["launch"]["returns_written_to"] == "device memory"
     assert forced["generation_cost_checksum"] == plain["generation_cost_checksum"]
     assert plain["collective"] is None            # --no-extras: no collective anywhere in a plain one-GPU run
+
+
+def test_two_ranks_carry_baseline_configs_4_and_5_with_parity():
+    """at N > 1 the line holds BASELINE configs 4 / 5 AS STATED -- the fixed population split into
+    N candidate blocks, the gather inside the timed step -- and every BASELINE block an untimed oracle parity object whose
+    counts are summed over the ranks.  Two gloo ranks on the one card: 8 192 / 16 384 episodes per rank, the same
+    generation costs as the whole population on one rank, every checked episode bit-identical to the oracle."""
+    port = 30500 + os.getpid() % 200
+    two = run(["--gpus", "2", "--backend", "gloo", "--master-port", str(port), "--steps", "3", "--warmup", "1",
+               "--no-cpu-baseline"], timeout=900)
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["config"]["episodes_per_gpu"] == 2048
+    c4, c5 = two["config4"], two["config5"]
+    assert c4["scaling"] == c5["scaling"] == "strong"
+    assert c4["episodes_per_generation"] == 16384 and c4["episodes_per_gpu"] == 8192 and "H=15" in c4["workload"]
+    assert c5["episodes_per_generation"] == 32768 and c5["episodes_per_gpu"] == 16384 and "H=25" in c5["workload"]
+    for b in (c4, c5):
+        assert b["collective"]["ranks_seen"] == 2 and b["collective"]["in_timed_step"] is True
+        assert len(b["roofline"]["launch"]["kernel_ms_per_rank"]) == 2 and min(b["roofline"]["launch"]["kernel_ms_per_rank"]) > 0
+        assert abs(b["value"] - b["episodes_per_generation"] / (b["ms_per_step"] * 1e-3)) / b["value"] < 1e-6
+    for b in (two, two["config2"], c4, c5):
+        par = b["parity"]
+        assert par["episodes_checked"] >= 128 and par["bitwise_equal"] == par["episodes_checked"] == par["within_1e-4_rel"]
+        assert par["argmin_flips"] == 0 and par["plan_steps_checked"] > 0
+    assert two["parity"]["ranks"] == c4["parity"]["ranks"] == 2 and two["config2"]["parity"]["ranks"] == 1
+    assert two["parity"]["episodes_checked"] >= 256 and c5["parity"]["episodes_checked"] >= 256
+    # the same populations whole on one rank: identical generation costs
+    for c, blk in ((4, c4), (5, c5)):
+        one = run(["--gpus", "1", "--config", str(c), "--scaling", "strong", "--no-parity"] + COMMON)
+        assert one["config"]["episodes_per_generation"] == blk["episodes_per_generation"]
+        assert one["generation_cost_checksum"] == blk["generation_cost_checksum"], c
