@@ -518,6 +518,69 @@ def main():
                         "float64 reduction (native), NaN costs redrawn as pycma does, tell (native), pycma's "
                         "termination rules; own CMA-ES, pycma is not installed"}
 
+    def lockstep_block(name, spec, R=28, gens=48):
+        """R independent CMA-ES runs of a reference shape in LOCKSTEP, one indexed launch per generation
+        (MPC_ORD.optimize_cmaes_many; the reference's Pool over init groups, run_mpc_ord.py:83-90 -- 28 = the chosen
+        weight vectors of generalization_data.py:78-84): generation wall-clock for all R runs together."""
+        from l4dc_mpc_ocd_amd.interact_drive.experiments import run_mpc_ord as rmo
+        m = rmo.make_mpc_ord(spec["scenario"], horizon=spec["horizon"], n_inits=spec["n_inits"], seed=1, **spec.get("kwargs", {}))
+        scn = scenarios.SCENARIOS[spec["scenario"]](horizon=spec["horizon"], **spec.get("kwargs", {}))
+        runs = [(list(scn.init_dist.sample(spec["n_inits"], seed=300 + r)), 1 + r, 0.05) for r in range(R)]
+        res = m.optimize_cmaes_many(runs, maxiter=gens, termination={"tolfacupx": float("inf"), "tolupsigma": float("inf")})
+        wall = np.array(res.generation_wall_seconds[-32:]) * 1e3
+        nat = np.array(res.generation_seconds[-32:]) * 1e3
+        E = int(res.episodes_per_generation[-1])
+        # the launch by itself: HIP events on the launch stream (torch's current stream is the one the launches go to)
+        eng = m._engine()
+        pop = res.runs[0].es.lam
+        rows, p0, n0 = [], 0, 0
+        for init_states, _, _ in runs:
+            N_r = len(init_states)
+            rows += [(p0 + e // (N_r * scn.desc.n_samples), n0 + (e // scn.desc.n_samples) % N_r, e) for e in range(pop * N_r * scn.desc.n_samples)]
+            p0, n0 = p0 + pop, n0 + N_r
+        idx = torch.as_tensor(np.asarray(rows, dtype=np.int32)).to(device)
+        init_all = np.concatenate([np.asarray(r[0], dtype=np.float32).reshape(-1, 4) for r in runs])
+        w_all = np.concatenate([np.stack([scenarios.planner_weights_fp32(c) for c in scn.candidate_weights(pop, seed=400 + r)]) for r in range(R)])
+        init_dev, w_dev = torch.as_tensor(init_all).to(device), torch.as_tensor(w_all).to(device)
+        ret = torch.empty(len(rows), dtype=torch.float32, device=device)
+        from l4dc_mpc_ocd_amd import abi
+
+        def launch():
+            abi.check(eng.lib, eng.lib.ocd_rollout_indexed(eng._h, init_dev.data_ptr(), init_dev.shape[0], w_dev.data_ptr(), w_dev.shape[0],
+                                                           idx.data_ptr(), len(rows), ret.data_ptr(), None, None, eng._stream()))
+        for _ in range(5):
+            launch()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(10):
+            launch()
+        ev1.record()
+        ev1.synchronize()
+        out = {"workload": f"{R} independent CMA-ES runs of {spec['label']} in lockstep: one launch of {E} episodes per generation",
+               "runs": R, "episodes_per_generation": E, "lockstep": bool(res.lockstep),
+               "cma_generation_ms": float(np.median(wall)), "cma_generation_native_timers_ms": float(np.median(nat)),
+               "kernel_ms": ev0.elapsed_time(ev1) / 10, "launch": eng.last_launch(), "generations_run": len(res.generation_seconds),
+               "generations_timed": int(len(wall)), "host_split_ms": res.host_split_ms(),
+               "value": E / (float(np.median(wall)) * 1e-3), "unit": "episodes/s",
+               "stop_reason": sorted({k for o in res.runs for k in o.stop_reason}),
+               "sampler_parity": "unpinned (own CMA-ES, pycma absent); every run's history is bit for bit the run alone (tests/test_gpu_lockstep.py)"}
+        if not args.no_cpu_baseline:                                # the same R populations on the host's cores
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib
+            orc = oracle_lib.load()
+            cores = min(usable_cores(), int(os.environ.get("OCD_CPU_THREADS", "64")))
+            t0, n_ep, reps = time.perf_counter(), 0, 0
+            while time.perf_counter() - t0 < 2.0:
+                for r in range(R):
+                    orc.rollout(scn.desc, runs[r][0], w_all[r * pop:(r + 1) * pop], n_threads=cores)
+                n_ep += E
+                reps += 1
+            dt_c = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": n_ep / dt_c, "unit": "episodes/s", "cores": cores, "kind": "port",
+                                   "sample": f"{reps} x the {R} populations ({E} episodes), one oracle call per run with OpenMP over its "
+                                             f"episodes on {cores} threads, {dt_c:.1f} s of CPU work (oracle/ocd_oracle.c)"}
+        return out
+
     def block(cfg_index, dt, kern_ms, ctx, steps, per_gpu_only=False):
         cfg, scn, inits, w32, P, N, S, n_local, launch, _coll = ctx[:10]
         kernel_name = ("ocd::mpc_chunk_kernel" if launch["scan_mode"] == 4 else "ocd::mpc_kernel") + \
@@ -644,6 +707,12 @@ def main():
                 if not args.no_cpu_baseline:
                     b["cpu_baseline"] = cpu_baseline(ctx_r[1], ctx_r[2], ctx_r[3], budget_s=2.0)
                 reference_blocks[name] = b
+            # the reference's only parallel axis (a Pool over independent runs) as ONE launch per generation
+            lb = lockstep_block("reference_h5", REFERENCE_SHAPES["reference_h5"])
+            if "reference_h5" in reference_blocks:
+                lb["one_run_generation_ms"] = reference_blocks["reference_h5"]["cma_generation_ms"]
+                lb["generation_ms_ratio_to_one_run"] = lb["cma_generation_ms"] / lb["one_run_generation_ms"]
+            reference_blocks["reference_h5_x28"] = lb
 
     if rank == 0:
         cfg, scn, inits, w32, P, N, S, n_local = ctx[:8]

@@ -266,6 +266,29 @@ int32_t ocd_rollout_episodes(const ocd_scenario *scn,
                              void *hip_stream);
 
 /*
+ * Independent populations in ONE launch: the reference runs one optimisation per init group in a multiprocessing.Pool
+ * (experiments/run_mpc_ord.py:83-90; 28 chosen weight vectors x 32 held-out inits in generalization_data.py:78-107), each
+ * process looping MPC_ORD.eval_weights_for_init (mpc_ord.py:67-106) over ITS candidates and ITS init states.  Here the
+ * episodes of all those loops are rows of one index and run as one batch:
+ *
+ *   init_states   [N_rows, 4]   every run's init states, concatenated
+ *   cand_weights  [P_rows, D]   every run's candidates, concatenated (normalised fp32 as for ocd_rollout_episodes)
+ *   episode_index [E, 3] int32  per episode: row of cand_weights, row of init_states, and the number of the world.reset()
+ *                 call that starts it in ITS OWN sequential evaluation (= its flat index (p*N + n)*S + s inside its run,
+ *                 plus that run's reset_phase): selects the entry of the teleport cycle exactly as ocd_rollout_episodes
+ *                 does for episode e (reset % teleport_period, or reset % n_samples when the period is 0).
+ *                 Device-addressable memory (device or pinned host); rows outside [0, P_rows) / [0, N_rows) are clamped.
+ *   returns_out   [E]; traj_out [E, T+1, C, 4] or NULL; ctrl_out [E, T, 2] or NULL -- in index order.
+ * Episode i is bit for bit the episode ocd_rollout_episodes computes for the same (candidate, init, reset).
+ */
+int32_t ocd_rollout_indexed(const ocd_scenario *scn,
+                            const float *init_states, int64_t N_rows,
+                            const float *cand_weights, int64_t P_rows,
+                            const int32_t *episode_index, int64_t E,
+                            float *returns_out, float *traj_out, float *ctrl_out,
+                            void *hip_stream);
+
+/*
  * The same episode loop started from arbitrary world states instead of
  * world.reset(): n_steps control steps from world step index `first_step`
  * (selects the scripted cars' plan entries, fixed_plan_car.py:25-31, and the

@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 #define OCD_CMA_MAX_DIM 64
-#define OCD_CMA_ABI_VERSION 5      /* 2: tell returns the non-finite count; resample, stop_state, abi_version; 3: normalise_weights; 4: stop, run; 5: 12 stop rules (noeffectaxis, noeffectcoord), add_evals */
+#define OCD_CMA_ABI_VERSION 5      /* 2: tell returns the non-finite count; resample, stop_state, abi_version; 3: normalise_weights; 4: stop, run; 5: 12 stop rules (noeffectaxis, noeffectcoord), add_evals, run_many */
 #define OCD_CMA_N_STOP 12          /* termination rules of ocd_cma_stop */
 
 typedef struct ocd_cma ocd_cma;
@@ -111,6 +111,51 @@ typedef struct ocd_cma_run_args {
  * (ocd_cma_resample), tells, and calls again.  *generations_done = generations told in this call. */
 int32_t ocd_cma_run(ocd_cma *es, const ocd_cma_run_args *a, int64_t *generations_done, int32_t stop_flags[OCD_CMA_N_STOP],
                     int32_t *pending_nan);
+
+/* R independent optimisations in lockstep, ONE episode launch per generation: what the reference spreads over a
+ * multiprocessing.Pool -- one process per init group (experiments/run_mpc_ord.py:83-90), each looping pycma's ask /
+ * fitness / tell on its own population and init states (mpc_ord.py:33-45).  The episodes of all active runs are rows of one
+ * index and go through ocd_rollout_indexed (include/ocd.h); every run sees exactly the call sequence ocd_cma_run gives it
+ * alone, so its candidates, costs and history are bit for bit those of the run alone. */
+#define OCD_CMA_MAX_RUNS 256
+typedef int32_t (*ocd_cma_rollout_indexed_fn)(const void *scn, const float *init_states, int64_t N_rows,
+                                              const float *cand_weights, int64_t P_rows, const int32_t *episode_index,
+                                              int64_t E, float *returns_out, float *traj_out, float *ctrl_out, void *hip_stream);
+
+typedef struct ocd_cma_many_args {
+    const void *scn;              /* ocd_scenario handle */
+    const float *init_dev;        /* [N_rows, 4] device: every run's init states, concatenated */
+    int64_t N_rows, P_rows, S;    /* init rows, weight rows (sum of the popsizes), samples per init */
+    int32_t R;                    /* runs, <= OCD_CMA_MAX_RUNS; all of the same dimension n */
+    int32_t normalise_variant;    /* ocd_normalise_weights */
+    const int64_t *run_n0, *run_N;/* [R] first init row and number of inits of run r */
+    const int64_t *run_p0;        /* [R] first row of run r in w_pinned (it owns popsize_r rows) */
+    const int32_t *run_reset_phase; /* [R] world.reset() calls before run r's episode 0 (teleport cycle), or NULL = 0 */
+    float *w_pinned;              /* [P_rows, n] fp32, pinned host memory the device addresses */
+    int32_t *index_pinned;        /* [sum_r popsize_r N_r S, 3] pinned: rewritten here whenever a run drops out */
+    float *ret_pinned;            /* [same] pinned: the launch's returns, active runs in order */
+    void *stream;
+    ocd_cma_rollout_indexed_fn rollout;   /* ocd_rollout_indexed */
+    ocd_cma_sync_fn sync;                 /* ocd_stream_synchronize */
+    int64_t max_generations;      /* at most this many lockstep generations in this call */
+    const double *stop_opts;      /* [OCD_CMA_N_STOP] ocd_cma_stop options, the same for every run */
+    uint8_t *active;              /* [R] in / out: 1 = run r still takes part (cleared when a termination rule holds) */
+    double *const *X;             /* [R] pointers: run r's population [popsize_r, n] */
+    double *const *cost;          /* [R] pointers: its costs [popsize_r] */
+    double *hist_w;               /* [max_generations, P_rows, n] rows normalised once (history entries), or NULL */
+    double *hist_cost;            /* [max_generations, P_rows], or NULL */
+    uint8_t *evaluated;           /* [max_generations, R] 1 where run r took part in generation g (its rows are valid), or NULL */
+    double *seconds;              /* [max_generations, 8] as ocd_cma_run_args.seconds (all runs together), or NULL */
+    int32_t *nonfinite;           /* [max_generations, R] non-finite costs told, or NULL */
+    int64_t *episodes_launched;   /* [max_generations] episodes of each generation's launch, or NULL */
+    int32_t *stop_flags;          /* [R, OCD_CMA_N_STOP] out: the rules that ended run r in this call */
+    uint8_t *pending_nan;         /* [R] out: run r's last generation is evaluated (X, cost, history rows) but NOT told: a
+                                   * cost is NaN -- the caller redraws (ocd_cma_resample), tells it, and calls again */
+} ocd_cma_many_args;
+
+/* Returns after max_generations, when no run is active any more, or right after a generation in which some run got a
+ * NaN cost (pending_nan).  *generations_done = lockstep generations executed in this call. */
+int32_t ocd_cma_run_many(ocd_cma *const *es, const ocd_cma_many_args *a, int64_t *generations_done);
 
 /* K fitness evaluations of one fixed population back to back -- launch (a->rollout on the P rows of a->w_pinned, taken
  * as they are), wait (a->sync), float64 reduction into cost_out [P] -- without the interpreter between them: what a

@@ -101,6 +101,8 @@ HIP_SYMBOLS = [
      [_VP, _VP, _VP, _VP, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, _VP]),
     ("ocd_rollout_episodes", C.c_int32,
      [_VP, _VP, _VP, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _VP, _VP, _VP, _VP]),
+    ("ocd_rollout_indexed", C.c_int32,
+     [_VP, _VP, C.c_int64, _VP, C.c_int64, _VP, C.c_int64, _VP, _VP, _VP, _VP]),
     ("ocd_rollout_from_state", C.c_int32,
      [_VP, _VP, _VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _VP, _VP, _VP, C.c_int64, _VP]),
     ("ocd_mpc_reward_batch", C.c_int32,

@@ -457,6 +457,28 @@ int32_t ocd_rollout_episodes(const ocd_scenario *scn, const float *init_states, 
     return launch(scn, p, hip_stream);
 }
 
+int32_t ocd_rollout_indexed(const ocd_scenario *scn, const float *init_states, int64_t N_rows,
+                            const float *cand_weights, int64_t P_rows, const int32_t *episode_index, int64_t E,
+                            float *returns_out, float *traj_out, float *ctrl_out, void *hip_stream)
+{
+    if (!scn) return fail(OCD_ERR_INVALID_ARG, "scenario is NULL");
+    if (E < 0) return fail(OCD_ERR_INVALID_ARG, "E = %lld < 0", (long long)E);
+    if (E == 0) return OCD_OK;
+    if (!episode_index) return fail(OCD_ERR_INVALID_ARG, "episode_index is NULL");
+    ocd::KernelParams p;
+    // (the flat-range checks of rollout_params on a population of P_rows x N_rows; the launch then covers E index rows)
+    int32_t st = rollout_params(scn, init_states, cand_weights, P_rows, N_rows, 0, 0, returns_out, traj_out, ctrl_out, nullptr, p);
+    if (st != OCD_OK) return st;
+    p.n_problems = E;
+    p.ep_index = episode_index;
+    p.P_rows = P_rows;
+    st = need_device();
+    if (st != OCD_OK) return st;
+    st = scripted_plans_device(scn, (hipStream_t)hip_stream, &p.other_plans);
+    if (st != OCD_OK) return st;
+    return launch(scn, p, hip_stream);
+}
+
 int32_t ocd_rollout_from_state(const ocd_scenario *scn, const float *world_state,
                                const float *weights, int32_t weights_per_problem,
                                int32_t first_step, int32_t n_steps, int32_t sample,

@@ -642,6 +642,114 @@ int32_t ocd_cma_run(ocd_cma *es, const ocd_cma_run_args *a, int64_t *generations
     return 0;
 }
 
+/* ---- R independent runs in lockstep, one launch per generation -------------------------------------------------------
+ * The reference runs one optimisation per init group in a multiprocessing.Pool (run_mpc_ord.py:83-90): R processes, each
+ * looping ask -> fitness -> tell on its own population and its own init states.  Here the R strategies advance together
+ * and a generation's episodes -- sum over the active runs of popsize_r x N_r x S -- are ONE indexed launch
+ * (ocd_rollout_indexed): a single run of the reference's shape fills 81 of the chip's 1 024 SIMDs, 28 of them most of it,
+ * in the same wall time.  Every run goes through exactly the calls ocd_cma_run makes for it alone (ask, normalise,
+ * prepare, tell, stop, in that order, on its own state and random stream), so its history is bit for bit the history of
+ * the run alone; a run that stops drops out of the index, a run with a NaN cost is handed back untold (pending_nan[r])
+ * for the caller's rejection sampling while the others are told. */
+static void build_index(const ocd_cma_many_args *a, ocd_cma *const *es, int64_t *ret_off, int64_t *E_out)
+{
+    int64_t e = 0;
+    for (int r = 0; r < a->R; ++r) {
+        ret_off[r] = -1;
+        if (!a->active[r]) continue;
+        ret_off[r] = e;
+        const int64_t lam = es[r]->lam, N = a->run_N[r], phase = a->run_reset_phase ? a->run_reset_phase[r] : 0;
+        int64_t flat = 0;
+        for (int64_t p = 0; p < lam; ++p)
+            for (int64_t i = 0; i < N; ++i)
+                for (int64_t sidx = 0; sidx < a->S; ++sidx, ++flat, ++e) {
+                    int32_t *row = a->index_pinned + 3 * e;
+                    row[0] = (int32_t)(a->run_p0[r] + p);
+                    row[1] = (int32_t)(a->run_n0[r] + i);
+                    row[2] = (int32_t)(phase + flat);
+                }
+    }
+    *E_out = e;
+}
+
+int32_t ocd_cma_run_many(ocd_cma *const *es, const ocd_cma_many_args *a, int64_t *generations_done)
+{
+    if (!es || !a || !generations_done) return -1;
+    if (a->R < 1 || a->R > OCD_CMA_MAX_RUNS || !a->rollout || !a->sync || !a->w_pinned || !a->ret_pinned || !a->index_pinned ||
+        !a->run_n0 || !a->run_N || !a->run_p0 || !a->active || !a->X || !a->cost || !a->stop_flags || !a->pending_nan ||
+        !a->stop_opts || a->S < 1 || a->N_rows < 1 || a->P_rows < 1 || a->max_generations < 0 ||
+        a->normalise_variant < 0 || a->normalise_variant > 1) return -1;
+    const int R = a->R;
+    int n = 0;
+    for (int r = 0; r < R; ++r) {
+        if (!es[r] || !a->X[r] || !a->cost[r]) return -1;
+        if (r == 0) n = es[r]->n;
+        if (es[r]->n != n || a->run_N[r] < 1 || a->run_n0[r] < 0 || a->run_n0[r] + a->run_N[r] > a->N_rows ||
+            a->run_p0[r] < 0 || a->run_p0[r] + es[r]->lam > a->P_rows) return -1;
+        a->pending_nan[r] = 0;
+        for (int i = 0; i < OCD_CMA_N_STOP; ++i) a->stop_flags[(size_t)r * OCD_CMA_N_STOP + i] = 0;
+    }
+    *generations_done = 0;
+    int64_t ret_off[OCD_CMA_MAX_RUNS];
+    int64_t E = 0;
+    int dirty = 1;
+    for (int64_t g = 0; g < a->max_generations; ++g) {
+        int n_active = 0;
+        for (int r = 0; r < R; ++r) n_active += a->active[r] != 0;
+        if (!n_active) return 0;
+        double *sg = a->seconds ? a->seconds + 8 * g : NULL;
+        const double t0 = now_s();
+        for (int r = 0; r < R; ++r)
+            if (a->active[r] && ocd_cma_ask(es[r], a->X[r]) != 0) return -1;
+        const double t1 = now_s();
+        for (int r = 0; r < R; ++r)
+            if (a->active[r] && ocd_normalise_weights(a->X[r], es[r]->lam, n, a->normalise_variant,
+                                                      a->w_pinned + (size_t)a->run_p0[r] * n) != 0) return -1;
+        if (dirty) { build_index(a, es, ret_off, &E); dirty = 0; }
+        const double t2 = now_s();
+        const int32_t st = a->rollout(a->scn, a->init_dev, a->N_rows, a->w_pinned, a->P_rows, a->index_pinned, E,
+                                      a->ret_pinned, NULL, NULL, a->stream);
+        if (st != 0) return st < 0 ? st : -1;
+        if (a->episodes_launched) a->episodes_launched[g] = E;
+        const double t3 = now_s();
+        for (int r = 0; r < R; ++r) {                     /* while the GPU works */
+            if (a->evaluated) a->evaluated[(size_t)g * R + r] = a->active[r];
+            if (!a->active[r]) continue;
+            ocd_cma_prepare(es[r]);
+            if (a->hist_w)
+                for (int k = 0; k < es[r]->lam; ++k)
+                    row_normalise_once(a->X[r] + (size_t)k * n, n, a->normalise_variant,
+                                       a->hist_w + ((size_t)g * a->P_rows + a->run_p0[r] + k) * n);
+        }
+        const double t4 = now_s();
+        if (a->sync(a->stream) != 0) return -1;
+        const double t5 = now_s();
+        int any_pending = 0;
+        for (int r = 0; r < R; ++r) {
+            if (!a->active[r]) continue;
+            const int lam = es[r]->lam;
+            if (ocd_fitness_from_returns(a->ret_pinned + ret_off[r], lam, a->run_N[r], a->S, a->cost[r]) != 0) return -1;
+            if (a->hist_cost) memcpy(a->hist_cost + (size_t)g * a->P_rows + a->run_p0[r], a->cost[r], sizeof(double) * (size_t)lam);
+            int any_nan = 0;
+            for (int k = 0; k < lam; ++k) any_nan |= isnan(a->cost[r][k]);
+            if (any_nan) { a->pending_nan[r] = 1; any_pending = 1; }
+        }
+        const double t6 = now_s();
+        for (int r = 0; r < R; ++r) {
+            if (!a->active[r] || a->pending_nan[r]) continue;
+            const int32_t nonfinite = ocd_cma_tell(es[r], a->X[r], a->cost[r]);
+            if (nonfinite < 0) return -1;
+            if (a->nonfinite) a->nonfinite[(size_t)g * R + r] = nonfinite;
+            if (ocd_cma_stop(es[r], a->stop_opts, a->stop_flags + (size_t)r * OCD_CMA_N_STOP) > 0) { a->active[r] = 0; dirty = 1; }
+        }
+        const double t7 = now_s();
+        if (sg) { sg[1] = t1 - t0; sg[2] = t2 - t1; sg[3] = t3 - t2; sg[4] = t4 - t3; sg[5] = t5 - t4; sg[6] = t6 - t5; sg[7] = t7 - t6; sg[0] = t7 - t0; }
+        *generations_done = g + 1;
+        if (any_pending) return 0;            /* the caller redraws, tells those runs, and calls again */
+    }
+    return 0;
+}
+
 /* K fitness evaluations of one fixed population, back to back: launch, wait, float64 reduction -- the part of a
  * generation that bench.py times as its "step", through the same function pointers and without the interpreter between
  * steps.  The rows of a->w_pinned are evaluated as they are (already normalised fp32); cost_out [P] holds the last

@@ -71,7 +71,36 @@ struct KernelParams {
     unsigned long long *debug; // diagnostic builds only (OCD_STAMPS): per-wavefront cycle totals, else nullptr
     int32_t *launch_info;      // HOST pointer or nullptr: the launcher records its choice here (ocd_scenario_last_launch)
     int32_t dry_run;           // 1 = choose and record, launch nothing (ocd_scenario_plan_launch: no device needed)
+    // ROLLOUT, indexed (ocd_rollout_indexed): episode `prob` = (weight row, init row, reset number) of ep_index[prob],
+    // instead of the flat (p, n, s) decomposition of ep_begin + prob; rows are clamped to [0, P_rows) / [0, N)
+    const int32_t *ep_index;   // [n_problems, 3] or nullptr
+    long long P_rows;          // rows of `weights` (indexed rollouts only)
 };
+
+// Which (candidate row, init row, entry of the teleport cycle) episode `prob` of a rollout launch runs (both planner
+// kernels): the flat index e = ep_begin + prob = (p * N + n) * S + s of ocd_rollout_episodes, or row `prob` of the
+// caller's episode index (ocd_rollout_indexed: independent populations evaluated by one launch).
+__device__ __forceinline__ void episode_rows(const KernelParams &p, long long prob, long long &p_, long long &n_, int &tp_idx)
+{
+    const int period = p.d.teleport_period;
+    if (p.ep_index) {
+        const int32_t *ix = p.ep_index + 3 * prob;
+        long long pr = ix[0], nr = ix[1], reset = ix[2];
+        pr = pr < 0 ? 0 : (pr >= p.P_rows ? p.P_rows - 1 : pr);
+        nr = nr < 0 ? 0 : (nr >= p.N ? p.N - 1 : nr);
+        reset = reset < 0 ? 0 : reset;
+        p_ = pr; n_ = nr;
+        tp_idx = (int)(reset % (period > 0 ? period : p.S));
+    } else {
+        const long long e_glob = p.ep_begin + prob;           // flat (p, n, s) index
+        const long long s_ = e_glob % p.S;
+        n_ = (e_glob / p.S) % p.N;
+        p_ = e_glob / ((long long)p.S * p.N);
+        // ReplanningCarWorld.reset() toggles the removed car on EVERY reset (replanning_world.py:24-27):
+        // episode e of a sequential evaluation is reset number reset_phase + e
+        tp_idx = period > 0 ? (int)((p.reset_phase + e_glob) % period) : (int)s_;
+    }
+}
 
 // the launchers' only way to start a planner kernel: nothing is launched in a dry run
 #define OCD_LAUNCH(KERNEL, GRID, BLOCK, LDS, STREAM, P) \

@@ -191,11 +191,8 @@ mpc_kernel(const KernelParams p)
     float w[OCD_MAX_FEATURES];
     int tp_idx = 0;                           // which entry of the teleport cycle applies to this episode
     if (p.mode == OCD_MODE_ROLLOUT && !p.from_state) {
-        const long long e_glob = p.ep_begin + prob;           // flat (p, n, s) index
-        const long long s_ = e_glob % p.S, n_ = (e_glob / p.S) % p.N, p_ = e_glob / ((long long)p.S * p.N);
-        // ReplanningCarWorld.reset() toggles the removed car on EVERY reset (replanning_world.py:24-27):
-        // episode e of a sequential evaluation is reset number reset_phase + e
-        tp_idx = d.teleport_period > 0 ? (int)((p.reset_phase + e_glob) % d.teleport_period) : (int)s_;
+        long long p_, n_;
+        episode_rows(p, prob, p_, n_, tp_idx);                // flat (p, n, s) index, or the caller's episode index
         const float *ini = p.ego_states + 4 * n_;
         ex = ini[0]; ey = ini[1]; ev = ini[2]; eth = ini[3];
 #pragma unroll

@@ -220,6 +220,34 @@ class Engine(DeviceOps):
             out = {k: v.cpu().numpy() for k, v in out.items()}
         return out
 
+    def rollout_indexed(self, init_states, cand_weights, episode_index, want_traj: bool = False,
+                        to_numpy: bool = True) -> Dict[str, object]:
+        """Independent populations in one launch (include/ocd.h: ocd_rollout_indexed; the reference's Pool over init
+        groups, run_mpc_ord.py:83-90): episode i runs candidate row episode_index[i, 0] on init row [i, 1] as reset
+        number [i, 2] of its own sequential evaluation.  init_states [N_rows, 4], cand_weights [P_rows, D] (fp32,
+        normalised), episode_index [E, 3] int32."""
+        d = self.desc
+        init = self._to_dev(init_states).reshape(-1, 4)
+        w = self._to_dev(cand_weights).reshape(-1, max(d.n_features, 1))
+        idx = np.ascontiguousarray(np.asarray(episode_index, dtype=np.int32).reshape(-1, 3))
+        if idx.size and (idx[:, 0].min() < 0 or idx[:, 0].max() >= w.shape[0] or idx[:, 1].min() < 0 or
+                         idx[:, 1].max() >= init.shape[0] or idx[:, 2].min() < 0):
+            raise ValueError("episode_index names a candidate / init row that does not exist, or a negative reset number")
+        idx_dev = torch.as_tensor(idx).to(self.device)
+        E, T = idx.shape[0], d.episode_len
+        ret = torch.empty((E,), dtype=torch.float32, device=self.device)
+        traj = torch.empty((E, T + 1, d.n_cars, 4), dtype=torch.float32, device=self.device) if want_traj else None
+        ctrl = torch.empty((E, T, 2), dtype=torch.float32, device=self.device) if want_traj else None
+        self._call(self.lib.ocd_rollout_indexed, self._h, _ptr(init), init.shape[0], _ptr(w), w.shape[0], _ptr(idx_dev), E,
+                   _ptr(ret), _ptr(traj), _ptr(ctrl), self._stream())
+        out = dict(returns=ret)
+        if want_traj:
+            out.update(traj=traj, ctrl=ctrl)
+        if to_numpy:
+            torch.cuda.synchronize(self.device)
+            out = {k: v.cpu().numpy() for k, v in out.items()}
+        return out
+
     def rollout_from_state(self, world_state, weights, first_step: int, n_steps: int, sample: int = 0,
                            to_numpy: bool = True) -> Dict[str, object]:
         """n_steps CarWorld.step() calls from arbitrary world states [B, C, 4] (world step index first_step)."""

@@ -50,11 +50,33 @@ def make_mpc_ord(scenario, horizon=None, n_inits=1, seed=1, save_path=None, **sc
                    num_samples=scn.desc.n_samples)
 
 
+def _save_path(car, init_states, args, optimization_seed):
+    return (f'{args.optimizer}_{args.scenario}__designer_weights_{fmt(car.weights)}__'
+            f'{args.n_inits if not args.one_by_one else fmt(init_states[0])}_init_seed_{args.seed}'
+            f'_opt_seed_{optimization_seed}_sigma_{args.sigma}.pkl')
+
+
+def run_opts_lockstep(env, groups_and_seeds, args):
+    """What the reference's Pool(len(groups)).map(run_opt, ...) does (run_mpc_ord.py:83-90): one CMA-ES optimisation per
+    (init group, optimisation seed) -- here advanced in lockstep, ONE episode launch per generation for all of them
+    (reward_design.mpc_ord.optimize_cmaes_lockstep).  Returns [(mpc_ord, best), ...] in the order given."""
+    from ..reward_design.mpc_ord import optimize_cmaes_lockstep
+    car, world, _ = env['make_env'](debug=True)
+    ords = [MPC_ORD(world, car, group, env['eval_horizon'], num_samples=env['num_eval_samples'],
+                    save_path=_save_path(car, group, args, seed) if args.save else None)
+            for group, seed in groups_and_seeds]
+    res = optimize_cmaes_lockstep(ords, [seed for _, seed in groups_and_seeds], [args.sigma] * len(ords),
+                                  popsize=args.popsize, maxiter=args.maxiter, maxfevals=args.maxfevals)
+    if res.lockstep and res.generation_wall_seconds:
+        print(f'{len(ords)} runs in lockstep: {len(res.generation_seconds)} generations, up to '
+              f'{max(res.episodes_per_generation)} episodes per launch, median generation wall-clock '
+              f'{np.median(res.generation_wall_seconds) * 1e3:.2f} ms for all runs together')
+    return list(zip(res.runs, res.best))
+
+
 def run_opt(env, init_states, args, optimization_seed):
     car, world, _ = env['make_env'](debug=True)
-    save_path = (f'{args.optimizer}_{args.scenario}__designer_weights_{fmt(car.weights)}__'
-                 f'{args.n_inits if not args.one_by_one else fmt(init_states[0])}_init_seed_{args.seed}'
-                 f'_opt_seed_{optimization_seed}_sigma_{args.sigma}.pkl')
+    save_path = _save_path(car, init_states, args, optimization_seed)
     mpc_ord = MPC_ORD(world, car, init_states, env['eval_horizon'], num_samples=env['num_eval_samples'],
                       save_path=save_path if args.save else None)
     if args.optimizer == 'random':
@@ -82,6 +104,10 @@ def main(argv=None):
     parser.add_argument('--maxiter', type=int, default=None)
     parser.add_argument('--maxfevals', type=int, default=85, help='CMA-ES evaluations (85 are used in the paper plots)')
     parser.add_argument('--save', action='store_true', help='write the (weights, reward) history pickle')
+    parser.add_argument('--opt_seeds', type=int, nargs='+', default=None,
+                        help='several CMA-ES seeds: one optimisation per (init group, seed), all in lockstep')
+    parser.add_argument('--sequential', action='store_true',
+                        help='run the optimisations one after another instead of in lockstep (same results)')
     args = parser.parse_args(argv)
     assert args.n_inits >= 1
     assert args.seed != 0, 'CMA doesn\'t accept 0 seed'
@@ -97,9 +123,14 @@ def main(argv=None):
     car, world, init_states = env['make_env'](env_seeds=env_seeds, debug=True)
     init_states_groups = [[s] for s in init_states] if args.one_by_one else [init_states]
     print('init_states:', init_states_groups)
+    opt_seeds = args.opt_seeds or [optimization_seed]
+    jobs = [(group, seed) for group in init_states_groups for seed in opt_seeds]
+    if args.optimizer == 'cmaes' and len(jobs) > 1 and not args.sequential:
+        pairs = run_opts_lockstep(env, jobs, args)                  # the reference's Pool over groups, as ONE launch per generation
+    else:
+        pairs = [run_opt(env, group, args, seed) for group, seed in jobs]
     results = []
-    for group in init_states_groups:
-        mpc_ord, best = run_opt(env, group, args, optimization_seed)
+    for mpc_ord, best in pairs:
         finite = [h for h in mpc_ord.history if np.isfinite(h[1])]
         top = max(finite or mpc_ord.history, key=lambda a: a[1])
         print(f'evaluations {len(mpc_ord.history)}  designer-weights reward {mpc_ord.history[0][1]:.6f}  '

@@ -285,6 +285,21 @@ class RunArgs(C.Structure):
                 ("hist_w", C.c_void_p), ("hist_cost", C.c_void_p), ("seconds", C.c_void_p), ("nonfinite", C.c_void_p)]
 
 
+class RunManyArgs(C.Structure):
+    """struct ocd_cma_many_args (include/ocd_cma.h): R runs in lockstep, one indexed launch per generation."""
+    _fields_ = [("scn", C.c_void_p), ("init_dev", C.c_void_p), ("N_rows", C.c_int64), ("P_rows", C.c_int64), ("S", C.c_int64),
+                ("R", C.c_int32), ("normalise_variant", C.c_int32),
+                ("run_n0", C.c_void_p), ("run_N", C.c_void_p), ("run_p0", C.c_void_p), ("run_reset_phase", C.c_void_p),
+                ("w_pinned", C.c_void_p), ("index_pinned", C.c_void_p), ("ret_pinned", C.c_void_p), ("stream", C.c_void_p),
+                ("rollout", C.c_void_p), ("sync", C.c_void_p), ("max_generations", C.c_int64), ("stop_opts", C.c_void_p),
+                ("active", C.c_void_p), ("X", C.c_void_p), ("cost", C.c_void_p), ("hist_w", C.c_void_p),
+                ("hist_cost", C.c_void_p), ("evaluated", C.c_void_p), ("seconds", C.c_void_p), ("nonfinite", C.c_void_p),
+                ("episodes_launched", C.c_void_p), ("stop_flags", C.c_void_p), ("pending_nan", C.c_void_p)]
+
+
+MAX_RUNS = 256                                                       # OCD_CMA_MAX_RUNS
+
+
 def load_cma_library():
     """dlopen csrc/libocd_cma.so (built by `make -C csrc`, plain C) and bind include/ocd_cma.h."""
     global _CMA_LIB
@@ -353,6 +368,8 @@ def load_cma_library():
     lib.ocd_eval_generations.argtypes = [C.POINTER(RunArgs), C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_double)]
     lib.ocd_cma_run.restype = C.c_int32
     lib.ocd_cma_run.argtypes = [C.c_void_p, C.POINTER(RunArgs), C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int32)]
+    lib.ocd_cma_run_many.restype = C.c_int32
+    lib.ocd_cma_run_many.argtypes = [C.c_void_p, C.POINTER(RunManyArgs), C.POINTER(C.c_int64)]
     lib.ocd_cma_state.restype = C.c_int32
     lib.ocd_cma_state.argtypes = [C.c_void_p, _D, _D, _D, _D, _D, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _D]
     lib.ocd_fitness_from_returns.restype = C.c_int32

@@ -459,6 +459,18 @@ class MPC_ORD:
             f[rows] = self.eval_population(Xr)
         return f
 
+    def optimize_cmaes_many(self, runs, popsize=None, maxiter=None, maxfevals=None, termination=None, save_paths=None):
+        """R independent optimize_cmaes runs over this world and car -- `runs` = [(init_states, seed, sigma0), ...], what
+        the reference hands to a multiprocessing.Pool, one process per init group (run_mpc_ord.py:83-90) -- advanced in
+        LOCKSTEP with one episode launch per generation (optimize_cmaes_lockstep).  Returns a LockstepResult; its `.runs`
+        are R MPC_ORD objects, each with the history, stop_reason, es and counters the run would have alone."""
+        ords = []
+        for k, (init_states, _seed, _sigma0) in enumerate(runs):
+            ords.append(MPC_ORD(self.world, self.car, init_states, self.designer_horizon,
+                                save_path=None if save_paths is None else save_paths[k], num_samples=self.num_samples))
+        return optimize_cmaes_lockstep(ords, [r[1] for r in runs], [r[2] for r in runs], popsize=popsize, maxiter=maxiter,
+                                       maxfevals=maxfevals, termination=termination)
+
     def optimize_random_search(self, n_iter=1000, seed=1):
         """mpc_ord.py:47-65: same candidate stream (np.random.rand under np.random.seed), one launch."""
         self.history.seed = seed
@@ -485,6 +497,173 @@ class MPC_ORD:
 
 
 _install_reference_path_finder()
+
+
+class LockstepResult:
+    """What optimize_cmaes_lockstep returns: `runs` (the MPC_ORD objects, in order), `best` (their best candidates),
+    `lockstep` (True: one launch per generation for all runs; False: the runs were made one after another),
+    `generation_seconds` / `generation_wall_seconds` (per lockstep generation: native timers / including the
+    interpreter's bookkeeping), `episodes_per_generation` (episodes of each generation's launch), `host_split`
+    (seconds per segment and generation, as MPC_ORD.host_split), `launch` (what the last launch chose)."""
+
+    def __init__(self, runs):
+        self.runs, self.best, self.lockstep = runs, [], True
+        self.generation_seconds, self.generation_wall_seconds, self.episodes_per_generation = [], [], []
+        self.host_split, self.launch = {}, None
+
+    def host_split_ms(self):
+        return {k: float(np.median(v[-32:]) * 1e3) for k, v in self.host_split.items()}
+
+
+def optimize_cmaes_lockstep(ords, seeds, sigma0s, popsize=None, maxiter=None, maxfevals=None, termination=None, chunk=32):
+    """MPC_ORD.optimize_cmaes (mpc_ord.py:33-45) for R MPC_ORD objects over the SAME world, car and planner -- their init
+    states, seeds and step sizes differ -- with the generation's episodes of ALL runs in one launch.
+
+    The reference's only parallel axis is a process pool over such runs (run_mpc_ord.py:83-90 --one_by_one; 28 chosen
+    weights in generalization_data.py:78-84).  One run of the reference's shape (popsize 9 x 3 inits = 27 episodes) keeps
+    81 of the chip's 1 024 SIMDs busy for ~1.1 ms per generation; R runs in lockstep take the same wall time per
+    generation until the launch outgrows one wavefront per SIMD.  Each run makes exactly the calls it makes alone
+    (csrc/ocd_cma.c: ocd_cma_run_many vs ocd_cma_run -- ask, normalise, prepare, tell, stop on its own state and random
+    stream; NaN costs redrawn by the same Python code), so histories, pickles, stop reasons and counters are bit for
+    bit those of the runs made one after another; a run that stops drops out of the launch.
+
+    Falls back to making the runs one after another (same results) when lockstep is not possible: under
+    torch.distributed with more than one rank, with force_python_loop, or where the native weight normalisation does
+    not reproduce numpy's on this machine."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    from .cmaes import MAX_RUNS, RunManyArgs, STOP_NAMES, N_STOP, load_cma_library
+    from ...scenarios import _native_normalise_variant
+    R = len(ords)
+    if not (R == len(seeds) == len(sigma0s)) or R < 1:
+        raise ValueError("one seed and one sigma0 per run")
+    res = LockstepResult(list(ords))
+    first = ords[0]
+    D = first.weight_dim
+    engines = [o._engine() for o in ords]
+    overrides = dict(maxiter=maxiter, maxfevals=maxfevals, **(termination or {}))
+    sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    odd = any(hasattr(o.world, "unlucky_car_idx") and (len(o.init_car_states) * o.num_samples) % 2 for o in ords)
+    if (any(e is not engines[0] for e in engines) or any(o.weight_dim != D or o.num_samples != first.num_samples for o in ords)):
+        raise ValueError("optimize_cmaes_lockstep: the runs must share world, car, planner arguments and num_samples")
+    if (sharded or R > MAX_RUNS or odd or _native_normalise_variant(D) is None
+            or any(getattr(o, "force_python_loop", False) for o in ords)):
+        res.lockstep = False
+        for o, seed, sigma0 in zip(ords, seeds, sigma0s):
+            res.best.append(o.optimize_cmaes(seed=seed, sigma0=sigma0, popsize=popsize, maxiter=maxiter, maxfevals=maxfevals,
+                                             termination=termination))
+            res.generation_seconds.extend(o.generation_seconds)
+            res.generation_wall_seconds.extend(o.generation_wall_seconds)
+        return res
+    eng = engines[0]
+    lib = load_cma_library()
+    ess = []
+    for o, seed, sigma0 in zip(ords, seeds, sigma0s):                  # the head of optimize_cmaes, per run
+        o.history.seed = seed
+        assert seed != 0
+        assert not o.done
+        o.should_save_history = True
+        o.eval_weights(o.designer_weights)                             # "Iteration 0" baseline
+        ess.append(NativeCMAES(list(o.designer_weights), sigma0, popsize=popsize, seed=seed))
+        o.generation_seconds, o.generation_wall_seconds, o.fitness_seconds = [], [], []
+        o.host_split, o.n_resampled, o.stop_reason = {}, 0, {}
+        o._eng_fixed = eng
+    S = first.num_samples
+    lams = np.array([es.lam for es in ess], dtype=np.int64)
+    run_N = np.array([len(o.init_car_states) for o in ords], dtype=np.int64)
+    run_n0 = np.concatenate([[0], np.cumsum(run_N)[:-1]]).astype(np.int64)
+    run_p0 = np.concatenate([[0], np.cumsum(lams)[:-1]]).astype(np.int64)
+    P_rows, N_rows = int(lams.sum()), int(run_N.sum())
+    E_max = int((lams * run_N).sum() * S)
+    try:
+        with torch.cuda.device(eng.device):
+            inits = np.concatenate([np.asarray(o.init_car_states, dtype=np.float32).reshape(-1, 4) for o in ords])
+            init_dev = torch.as_tensor(np.ascontiguousarray(inits)).to(eng.device)
+            w_host = torch.empty((P_rows, D), dtype=torch.float32).pin_memory()
+            idx_host = torch.empty((E_max, 3), dtype=torch.int32).pin_memory()
+            ret_host = torch.empty((E_max,), dtype=torch.float32).pin_memory()
+            hist_w = np.empty((chunk, P_rows, D), dtype=np.float64)
+            hist_c = np.empty((chunk, P_rows), dtype=np.float64)
+            evaluated = np.zeros((chunk, R), dtype=np.uint8)
+            secs = np.zeros((chunk, 8), dtype=np.float64)
+            nonf = np.zeros((chunk, R), dtype=np.int32)
+            launched = np.zeros(chunk, dtype=np.int64)
+            active = np.ones(R, dtype=np.uint8)
+            pending = np.zeros(R, dtype=np.uint8)
+            flags = np.zeros((R, N_STOP), dtype=np.int32)
+            opts = ess[0]._stop_opts(overrides)
+            stop_opts = np.array([opts.get(k, 0.0) for k in STOP_NAMES], dtype=np.float64)
+            X_ptrs = (C.c_void_p * R)(*[es._X_ptr for es in ess])
+            f_ptrs = (C.c_void_p * R)(*[es._f_ptr for es in ess])
+            es_ptrs = (C.c_void_p * R)(*[es._h.value for es in ess])
+            a = RunManyArgs()
+            a.scn, a.init_dev, a.N_rows, a.P_rows, a.S, a.R = eng._h.value, init_dev.data_ptr(), N_rows, P_rows, S, R
+            a.normalise_variant = _native_normalise_variant(D)
+            a.run_n0, a.run_N, a.run_p0, a.run_reset_phase = run_n0.ctypes.data, run_N.ctypes.data, run_p0.ctypes.data, None
+            a.w_pinned, a.index_pinned, a.ret_pinned = w_host.data_ptr(), idx_host.data_ptr(), ret_host.data_ptr()
+            a.stream = torch.cuda.current_stream().cuda_stream
+            a.rollout = C.cast(eng.lib.ocd_rollout_indexed, C.c_void_p).value
+            a.sync = C.cast(eng.lib.ocd_stream_synchronize, C.c_void_p).value
+            a.max_generations = chunk
+            a.stop_opts, a.active = stop_opts.ctypes.data, active.ctypes.data
+            a.X, a.cost = C.cast(X_ptrs, C.c_void_p).value, C.cast(f_ptrs, C.c_void_p).value
+            a.hist_w, a.hist_cost, a.evaluated = hist_w.ctypes.data, hist_c.ctypes.data, evaluated.ctypes.data
+            a.seconds, a.nonfinite, a.episodes_launched = secs.ctypes.data, nonf.ctypes.data, launched.ctypes.data
+            a.stop_flags, a.pending_nan = flags.ctypes.data, pending.ctypes.data
+            names = ("ask", "normalise", "launch", "overlapped_bookkeeping", "kernel_gather_readback", "reduce", "tell")
+            done = C.c_int64(0)
+            while active.any():
+                t_chunk = time.perf_counter()
+                st = lib.ocd_cma_run_many(es_ptrs, C.byref(a), C.byref(done))
+                if st != 0:
+                    raise RuntimeError(f"ocd_cma_run_many -> {st}: {eng.lib.ocd_last_error().decode()}")
+                G = int(done.value)
+                for g in range(G):
+                    for r in np.nonzero(evaluated[g])[0]:
+                        o, p0, lam = ords[r], int(run_p0[r]), int(lams[r])
+                        o.history.extend(zip(hist_w[g, p0:p0 + lam].copy(), -hist_c[g, p0:p0 + lam]))   # mpc_ord.py:146
+                        o.iter += lam
+                        o.generation_seconds.append(float(secs[g, 0]))
+                        if not (g == G - 1 and pending[r]):
+                            o.n_nonfinite.append(int(nonf[g, r]))
+                    res.generation_seconds.append(float(secs[g, 0]))
+                    res.episodes_per_generation.append(int(launched[g]))
+                    for k, name in enumerate(names):
+                        res.host_split.setdefault(name, []).append(float(secs[g, 1 + k]))
+                for r in np.nonzero(pending)[0]:                       # pycma's rejection sampling, as the run alone does it
+                    o, es = ords[r], ess[r]
+                    f = es._f.copy()
+                    o.n_nonfinite.append(int(lams[r]) - int(np.isfinite(f).sum()))
+                    f = o._resample_nan(es, es._X, f)
+                    o._flush_history()
+                    es.tell(es._X, f)
+                    why = es.stop(**overrides)
+                    if why:
+                        active[r] = 0
+                        o.stop_reason = why
+                for r in range(R):
+                    if flags[r].any():
+                        ords[r].stop_reason = {k: opts.get(k) for i, k in enumerate(STOP_NAMES) if flags[r, i]}
+                if G:
+                    res.generation_wall_seconds.extend([(time.perf_counter() - t_chunk) / G] * G)
+                for o in ords:                                         # a saved history is complete after every native call
+                    if o.save_path is not None:
+                        o.save_history()
+            res.launch = eng.last_launch()
+    finally:
+        for o, es in zip(ords, ess):
+            o._eng_fixed = None
+            o._init_np_cache = None
+            o._flush_history()
+            o.es = es
+    for o, es in zip(ords, ess):
+        o.should_save_history = False
+        o.done = True
+        es.lib.ocd_cma_stop_state(es._h, es._ss_ptr)
+        es.last_nonfinite, es.nonfinite_total = int(es._ss[8]), int(es._ss[9])
+        res.best.append(es.best_x)
+    return res
 
 
 def finite_horizon_env(horizon=5, env_seeds=[1], debug=True, extra_inits=False):

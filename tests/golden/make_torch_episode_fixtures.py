@@ -102,7 +102,7 @@ CASES = {
 
 # seeds of the designer + 0.05 N(0, I) candidate draws (explicit: adding a case must not move the others')
 CANDIDATE_SEEDS = {"finite_horizon_h5": 100, "finite_horizon_h6": 101, "local_opt_h5": 102, "local_opt_h5_extra": 103,
-                   "merging_h5": 104, "replanning_h5": 105, "finite_horizon_h10": 100, "local_opt_h10": 104,
+                   "merging_h5": 104, "replanning_h5": 105, "finite_horizon_h10": 100, "local_opt_h10": 103,
                    "replanning_h10": 106, "merging_h10": 107, "replanning_h15": 108, "merging_h25": 109}
 
 

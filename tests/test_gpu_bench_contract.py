@@ -69,6 +69,12 @@ def test_bench_json_line():
     for rb in (r5, r6):
         assert rb["cma"]["popsize"] == 9 and rb["cma_generation_ms"] > rb["roofline"]["kernel_ms"] * 0.9
         assert rb["cpu_baseline"]["value"] > 0 and rb["cpu_baseline"]["kind"] == "port"
+    # 28 independent runs of the reference's shape in lockstep: one launch per generation, about the wall time of ONE run
+    x28 = d["reference_h5_x28"]
+    assert x28["runs"] == 28 and x28["episodes_per_generation"] == 28 * 27 and x28["lockstep"] is True
+    assert x28["generation_ms_ratio_to_one_run"] <= 1.3, x28
+    assert x28["kernel_ms"] <= x28["cma_generation_ms"] and x28["cpu_baseline"]["value"] > 0
+    assert x28["launch"]["workgroups"] >= 28 and x28["stop_reason"] == ["maxiter"]
     for blk in (d["config2"], s4, s5):
         assert blk["cpu_baseline"]["value"] > 0 and blk["cpu_baseline"]["cores"] >= 1
     # every block that names a BASELINE config carries an untimed parity object against the CPU oracle
