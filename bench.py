@@ -581,6 +581,69 @@ def main():
                                              f"episodes on {cores} threads, {dt_c:.1f} s of CPU work (oracle/ocd_oracle.c)"}
         return out
 
+    def config1_block(reps=40):
+        """BASELINE config 1 -- finite_horizon, 3 inits, the designer's ("true") weights, H = 5: the README's `vis` path
+        (run_mpc_ord.py:107-119: MPC_ORD.eval_weights(designer_weights)) through the SCALAR drop-in API, and the
+        object-by-object path under it (world.reset(); 15 x world.step(): PlannerCar._get_next_control ->
+        NaivePlanner.generate_plan -> Car.step, world.py:79-109, planner_car.py:54-85) -- plumbing latency, not
+        throughput; the CPU oracle on the same three episodes beside it."""
+        from l4dc_mpc_ocd_amd.interact_drive.reward_design.mpc_ord import MPC_ORD, finite_horizon_env
+        car, world, init_states = finite_horizon_env(horizon=5, env_seeds=[1000001, 1000002, 1000003])
+        m = MPC_ORD(world, car, init_states, 15)
+        cost = m.eval_weights(m.designer_weights)                  # (first call: handle, buffers)
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            c2 = m.eval_weights(m.designer_weights)
+            ts.append(time.perf_counter() - t0)
+        assert c2 == cost
+        # object by object: one episode = reset + 15 world.step() calls, each a plan launch + the real dynamics of every car
+        step_ts, ret_obj = [], []
+        w_designer = m.designer_weights
+        wn = w_designer / np.linalg.norm(w_designer)                # mpc_ord.py:120,71, then the car's setter: the
+        car.weights = wn / np.linalg.norm(wn)                      #   planner weights eval_weights would install
+        for init in init_states:
+            car.init_state = type(car.state)(init)
+            world.reset()
+            G = np.float32(0)
+            for _ in range(15):
+                t0 = time.perf_counter()
+                past, controls, _state = world.step()
+                step_ts.append(time.perf_counter() - t0)
+                G = np.float32(G + car.reward_fn(past, controls[car.index], weights=w_designer))
+            ret_obj.append(float(G))
+        scn = scenarios.finite_horizon(horizon=5)
+        eng = Engine(scn, device)
+        inits = np.asarray(init_states, dtype=np.float32)
+        w32 = scenarios.planner_weights_fp32(np.asarray(m.designer_weights, dtype=np.float64))[None]
+        init_dev, w_dev = torch.as_tensor(inits).to(device), torch.as_tensor(w32).to(device)
+        ret_dev = torch.empty(3, dtype=torch.float32, device=device)
+        kern = eng.time_rollout(init_dev, w_dev, 0, 3, ret_dev, reps=10)
+        out = {"workload": "BASELINE config 1: finite_horizon, 3 inits, designer weights, H=5, n_iter=100, K=3, T=15 -- "
+                           "MPC_ORD.eval_weights through the scalar drop-in API, and world.step() object by object",
+               "episodes": 3, "eval_weights_ms": float(np.median(ts) * 1e3), "kernel_ms": kern,
+               "world_step_ms": float(np.median(step_ts) * 1e3), "world_steps_timed": len(step_ts),
+               "episode_via_world_step_ms": float(np.sum(step_ts) / 3 * 1e3), "launch": eng.last_launch(),
+               "cost": float(cost)}
+        if not args.no_parity or not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib
+            orc = oracle_lib.load()
+            t0 = time.perf_counter()
+            n_rep = 0
+            while time.perf_counter() - t0 < 1.0:
+                ref = orc.rollout(scn.desc, inits, w32, n_threads=1)["returns"]
+                n_rep += 1
+            dt_c = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": 3 * n_rep / dt_c, "unit": "episodes/s", "cores": 1, "kind": "port",
+                                   "ms_per_eval_weights": dt_c / n_rep * 1e3,
+                                   "sample": f"{n_rep} x the 3 episodes, one thread (oracle/ocd_oracle.c)"}
+            want = float(sharding.fitness_from_returns(ref, 1, 3, 1)[0])
+            out["parity"] = {"episodes_checked": 3, "eval_weights_cost_bitwise_equal": bool(want == cost),
+                             "world_step_returns_bitwise_equal": bool(np.array_equal(np.asarray(ret_obj, dtype=np.float32), ref)),
+                             "against": "oracle/ocd_oracle.c, untimed"}
+        return out
+
     def block(cfg_index, dt, kern_ms, ctx, steps, per_gpu_only=False):
         cfg, scn, inits, w32, P, N, S, n_local, launch, _coll = ctx[:10]
         kernel_name = ("ocd::mpc_chunk_kernel" if launch["scan_mode"] == 4 else "ocd::mpc_kernel") + \
@@ -707,6 +770,7 @@ def main():
                 if not args.no_cpu_baseline:
                     b["cpu_baseline"] = cpu_baseline(ctx_r[1], ctx_r[2], ctx_r[3], budget_s=2.0)
                 reference_blocks[name] = b
+            reference_blocks["config1"] = config1_block()
             # the reference's only parallel axis (a Pool over independent runs) as ONE launch per generation
             lb = lockstep_block("reference_h5", REFERENCE_SHAPES["reference_h5"])
             if "reference_h5" in reference_blocks:

@@ -8,6 +8,7 @@ raises.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Dict, Optional
 
 import numpy as np
@@ -21,6 +22,22 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+# Calls whose arguments and results are small (one world.step() of the object-by-object API: a (C, 4) world state in, H
+# controls out) skip the copies altogether: the kernels read their inputs from and write their outputs to PINNED host
+# memory, which HIP maps into the device's address space -- a call is then "fill the staging arrays, launch, wait for an
+# event on the call's own stream, read the arrays" instead of 3-6 synchronous memcpys and a device-wide synchronisation.
+_SMALL_BYTES = 1 << 16
+_NP = {torch.float32: np.float32, torch.int32: np.int32}
+
+
+class _Staging(threading.local):
+    """Per-thread pinned staging tensors (two threads may share one Engine: tests/test_gpu_threads.py) and one event."""
+
+    def __init__(self):
+        self.bufs = {}
+        self.event = None
+
+
 class DeviceOps:
     """Scenario-independent device entry points (dynamics, math probes) on one GPU."""
 
@@ -29,12 +46,55 @@ class DeviceOps:
         if not torch.cuda.is_available():
             raise RuntimeError("no MI355X visible: the planner runs on the GPU only (no CPU fallback)")
         self.device = torch.device(device or f"cuda:{torch.cuda.current_device()}")
+        self._stage = _Staging()
 
     # ------------------------------------------------------------------ helpers
     def _to_dev(self, a, dtype=torch.float32) -> torch.Tensor:
         if isinstance(a, torch.Tensor):
             return a.to(device=self.device, dtype=dtype).contiguous()
         return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(self.device)
+
+    def _pinned(self, tag: str, shape, dtype) -> torch.Tensor:
+        key = (tag, tuple(int(v) for v in shape), dtype)
+        t = self._stage.bufs.get(key)
+        if t is None:
+            if len(self._stage.bufs) > 256:
+                self._stage.bufs.clear()
+            t = self._stage.bufs[key] = torch.empty(key[1], dtype=dtype).pin_memory()
+        return t
+
+    def _in(self, tag: str, a, shape, dtype=torch.float32, small: bool = True) -> torch.Tensor:
+        """An input the kernel can read: a device tensor as it is; host data through pinned staging when small (no copy
+        call), else uploaded."""
+        if isinstance(a, torch.Tensor) and a.is_cuda:
+            return a.to(device=self.device, dtype=dtype).contiguous().reshape(shape)
+        arr = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a
+        arr = np.ascontiguousarray(arr, dtype=_NP[dtype]).reshape(shape)
+        if small and arr.nbytes <= _SMALL_BYTES:
+            t = self._pinned(tag, arr.shape, dtype)
+            t.numpy()[...] = arr
+            return t
+        return torch.as_tensor(arr).to(self.device)
+
+    def _out(self, tag: str, shape, dtype=torch.float32, small: bool = True) -> torch.Tensor:
+        n = int(np.prod(shape)) * 4
+        if small and n <= _SMALL_BYTES:
+            return self._pinned(tag, shape, dtype)
+        return torch.empty(tuple(int(v) for v in shape), dtype=dtype, device=self.device)
+
+    def _wait(self) -> None:
+        """Block until what this thread queued on its current stream of this device is done: an event on the call's
+        own stream, not a device-wide synchronisation (other streams keep running)."""
+        ev = self._stage.event
+        if ev is None:
+            ev = self._stage.event = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        ev.synchronize()
+
+    @staticmethod
+    def _host(t: torch.Tensor) -> np.ndarray:
+        """After _wait(): the result as a numpy array the caller owns."""
+        return t.cpu().numpy() if t.is_cuda else t.numpy().copy()
 
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -45,16 +105,19 @@ class DeviceOps:
 
     def dynamics_batch(self, states, controls, dt: float, friction: float):
         """next_car_state for [B,4] states and [B,2] controls (simulation_utils.py:73-123)."""
-        st = self._to_dev(states).reshape(-1, 4)
-        u = self._to_dev(controls).reshape(-1, 2)
-        if u.shape[0] == 1 and st.shape[0] > 1:
-            u = u.expand(st.shape[0], 2).contiguous()
-        out = torch.empty_like(st)
+        st = self._in("dyn_s", states, (-1, 4))
+        if isinstance(controls, torch.Tensor):
+            controls = controls.detach().cpu().numpy()
+        cu = np.asarray(controls, dtype=np.float32).reshape(-1, 2)
+        if cu.shape[0] == 1 and st.shape[0] > 1:
+            cu = np.broadcast_to(cu, (st.shape[0], 2))
+        u = self._in("dyn_u", cu, (-1, 2))
+        out = self._out("dyn_o", st.shape)
         self._call(self.lib.ocd_dynamics_batch, _ptr(st), _ptr(u), float(np.float32(dt)),
                    float(np.float32(float(dt) ** 2)), float(np.float32(friction)), _ptr(out), st.shape[0],
                    self._stream())
-        torch.cuda.synchronize(self.device)
-        return out.cpu().numpy()
+        self._wait()
+        return self._host(out)
 
     def debug_math(self, x):
         xin = self._to_dev(x).reshape(-1)
@@ -157,25 +220,29 @@ class Engine(DeviceOps):
         """NaivePlanner.generate_plan for a batch of world states [B, C, 4].  init_speed [B]: the planning car's own
         current speed where it differs from the state the plan starts from (extra_inits, naive_planner.py:114)."""
         d = self.desc
-        ws = self._to_dev(world_state).reshape(-1, d.n_cars, 4)
+        sm = bool(to_numpy)                                        # results wanted as device tensors: no host staging
+        ws = self._in("plan_ws", world_state, (-1, d.n_cars, 4), small=sm)
         B = ws.shape[0]
         H, K = d.horizon, d.n_ctrl_inits
-        w = None if weights is None else self._to_dev(weights)
+        w = None
+        if weights is not None:
+            wdim = weights.dim() if isinstance(weights, torch.Tensor) else np.ndim(weights)
+            w = self._in("plan_w", weights, (-1, d.n_features) if wdim == 2 else (-1,), small=sm)
         per = int(w is not None and w.dim() == 2)
         if w is not None and per and w.shape[0] != B:
             raise ValueError(f"weights has {w.shape[0]} rows for {B} world states")
         if isinstance(other_plans, str):
             op = self._other_plans
         else:
-            op = None if other_plans is None else self._to_dev(other_plans).reshape(d.n_cars - 1, H, 2)
-        plans = torch.empty((B, H, 2), dtype=torch.float32, device=self.device)
-        loss = torch.empty((B,), dtype=torch.float32, device=self.device)
-        best = torch.empty((B,), dtype=torch.int32, device=self.device)
-        all_plans = torch.empty((B, K, H, 2), dtype=torch.float32, device=self.device) if want_all else None
-        all_losses = torch.empty((B, K), dtype=torch.float32, device=self.device) if want_all else None
+            op = None if other_plans is None else self._in("plan_op", other_plans, (d.n_cars - 1, H, 2), small=sm)
+        plans = self._out("plan_p", (B, H, 2), small=sm)
+        loss = self._out("plan_l", (B,), small=sm)
+        best = self._out("plan_b", (B,), torch.int32, small=sm)
+        all_plans = self._out("plan_ap", (B, K, H, 2), small=sm) if want_all else None
+        all_losses = self._out("plan_al", (B, K), small=sm) if want_all else None
         vs = None
         if init_speed is not None:
-            vs = self._to_dev(init_speed).reshape(-1)
+            vs = self._in("plan_vs", init_speed, (-1,), small=sm)
             if vs.shape[0] != B:
                 raise ValueError(f"init_speed has {vs.shape[0]} entries for {B} world states")
         self._call(self.lib.ocd_plan_batch_from, self._h, _ptr(ws), _ptr(vs), _ptr(w), per, _ptr(op), _ptr(plans),
@@ -184,8 +251,8 @@ class Engine(DeviceOps):
         if want_all:
             out.update(all_plans=all_plans, all_losses=all_losses)
         if to_numpy:
-            torch.cuda.synchronize(self.device)
-            out = {k: v.cpu().numpy() for k, v in out.items()}
+            self._wait()
+            out = {k: self._host(v) for k, v in out.items()}
         return out
 
     def rollout(self, init_states, cand_weights, ep_begin: int = 0, ep_end: Optional[int] = None,
@@ -195,29 +262,30 @@ class Engine(DeviceOps):
         cand_weights: [P, D] fp32, already normalised (scenarios.planner_weights_fp32).
         """
         d = self.desc
-        init = self._to_dev(init_states).reshape(-1, 4)
+        sm = bool(to_numpy)
+        init = self._in("ro_i", init_states, (-1, 4), small=sm)
         N = init.shape[0]
         if cand_weights is None:
             w, P = None, 1
         else:
-            w = self._to_dev(cand_weights).reshape(-1, d.n_features)
+            w = self._in("ro_w", cand_weights, (-1, d.n_features), small=sm)
             P = w.shape[0]
         E = P * N * d.n_samples
         if ep_end is None:
             ep_end = E
         n = ep_end - ep_begin
         T = d.episode_len
-        ret = torch.empty((max(n, 0),), dtype=torch.float32, device=self.device)
-        traj = torch.empty((n, T + 1, d.n_cars, 4), dtype=torch.float32, device=self.device) if want_traj else None
-        ctrl = torch.empty((n, T, 2), dtype=torch.float32, device=self.device) if want_traj else None
+        ret = self._out("ro_r", (max(n, 0),), small=sm)
+        traj = self._out("ro_t", (n, T + 1, d.n_cars, 4), small=sm) if want_traj else None
+        ctrl = self._out("ro_c", (n, T, 2), small=sm) if want_traj else None
         self._call(self.lib.ocd_rollout_episodes, self._h, _ptr(init), _ptr(w), P, N, ep_begin, ep_end,
                    _ptr(ret), _ptr(traj), _ptr(ctrl), self._stream())
         out = dict(returns=ret)
         if want_traj:
             out.update(traj=traj, ctrl=ctrl)
         if to_numpy:
-            torch.cuda.synchronize(self.device)
-            out = {k: v.cpu().numpy() for k, v in out.items()}
+            self._wait()
+            out = {k: self._host(v) for k, v in out.items()}
         return out
 
     def rollout_indexed(self, init_states, cand_weights, episode_index, want_traj: bool = False,
@@ -244,27 +312,31 @@ class Engine(DeviceOps):
         if want_traj:
             out.update(traj=traj, ctrl=ctrl)
         if to_numpy:
-            torch.cuda.synchronize(self.device)
-            out = {k: v.cpu().numpy() for k, v in out.items()}
+            self._wait()
+            out = {k: self._host(v) for k, v in out.items()}
         return out
 
     def rollout_from_state(self, world_state, weights, first_step: int, n_steps: int, sample: int = 0,
                            to_numpy: bool = True) -> Dict[str, object]:
         """n_steps CarWorld.step() calls from arbitrary world states [B, C, 4] (world step index first_step)."""
         d = self.desc
-        ws = self._to_dev(world_state).reshape(-1, d.n_cars, 4)
+        sm = bool(to_numpy)
+        ws = self._in("rfs_ws", world_state, (-1, d.n_cars, 4), small=sm)
         B = ws.shape[0]
-        w = None if weights is None else self._to_dev(weights)
+        w = None
+        if weights is not None:
+            wdim = weights.dim() if isinstance(weights, torch.Tensor) else np.ndim(weights)
+            w = self._in("rfs_w", weights, (-1, d.n_features) if wdim == 2 else (-1,), small=sm)
         per = int(w is not None and w.dim() == 2)
-        ret = torch.empty((B,), dtype=torch.float32, device=self.device)
-        traj = torch.empty((B, n_steps + 1, d.n_cars, 4), dtype=torch.float32, device=self.device)
-        ctrl = torch.empty((B, n_steps, 2), dtype=torch.float32, device=self.device)
+        ret = self._out("rfs_r", (B,), small=sm)
+        traj = self._out("rfs_t", (B, n_steps + 1, d.n_cars, 4), small=sm)
+        ctrl = self._out("rfs_c", (B, n_steps, 2), small=sm)
         self._call(self.lib.ocd_rollout_from_state, self._h, _ptr(ws), _ptr(w), per, first_step, n_steps, sample,
                    _ptr(ret), _ptr(traj), _ptr(ctrl), B, self._stream())
         out = dict(returns=ret, traj=traj, ctrl=ctrl)
         if to_numpy:
-            torch.cuda.synchronize(self.device)
-            out = {k: v.cpu().numpy() for k, v in out.items()}
+            self._wait()
+            out = {k: self._host(v) for k, v in out.items()}
         return out
 
     def time_rollout(self, init_dev: torch.Tensor, w_dev: torch.Tensor, ep_begin: int, ep_end: int,
@@ -283,15 +355,24 @@ class Engine(DeviceOps):
         """NaivePlanner.reward_func and its gradient for caller-supplied controls [B, H, 2]
         (naive_planner.py:33-77)."""
         d = self.desc
-        ws = self._to_dev(world_state).reshape(-1, d.n_cars, 4)
+        ws = self._in("obj_ws", world_state, (-1, d.n_cars, 4))
         B = ws.shape[0]
         H = d.horizon
-        u = self._to_dev(controls).reshape(-1, H, 2)
+        u = self._to_dev(controls).reshape(-1, H, 2) if B > 1 else self._in("obj_u", controls, (-1, H, 2))
         if u.shape[0] == 1 and B > 1:
             u = u.expand(B, H, 2).contiguous()
         if u.shape[0] != B:
             raise ValueError(f"controls has {u.shape[0]} rows for {B} world states")
-        w = None if weights is None else self._to_dev(weights)
+        w = None
+        if weights is not None:
+            if not isinstance(weights, torch.Tensor):
+                weights = np.asarray(weights, dtype=np.float32)
+            wdim = weights.dim() if isinstance(weights, torch.Tensor) else weights.ndim
+            if (weights.shape[-1] if wdim else 0) != d.n_features:
+                raise ValueError(f"weights has {weights.shape[-1] if wdim else 0} features, the scenario {d.n_features}")
+            w = self._in("obj_w", weights, (-1, d.n_features) if wdim == 2 else (-1,))
+            if wdim == 2 and w.shape[0] != B:
+                raise ValueError(f"weights has {w.shape[0]} rows for {B} world states")
         per = int(w is not None and w.dim() == 2)
         if w is not None and per and w.shape[0] != B:
             raise ValueError(f"weights has {w.shape[0]} rows for {B} world states")
@@ -300,27 +381,27 @@ class Engine(DeviceOps):
         if isinstance(other_plans, str):
             op = self._other_plans
         else:
-            op = None if other_plans is None else self._to_dev(other_plans).reshape(d.n_cars - 1, H, 2)
-        rew = torch.empty((B,), dtype=torch.float32, device=self.device)
-        grad = torch.empty((B, H, 2), dtype=torch.float32, device=self.device) if want_grad else None
-        traj = torch.empty((B, H, 4), dtype=torch.float32, device=self.device) if want_traj else None
+            op = None if other_plans is None else self._in("obj_op", other_plans, (d.n_cars - 1, H, 2))
+        rew = self._out("obj_r", (B,))
+        grad = self._out("obj_g", (B, H, 2)) if want_grad else None
+        traj = self._out("obj_t", (B, H, 4)) if want_traj else None
         self._call(self.lib.ocd_mpc_reward_batch, self._h, _ptr(ws), _ptr(w), per, _ptr(u), _ptr(op), _ptr(rew),
                    _ptr(grad), _ptr(traj), B, self._stream())
-        torch.cuda.synchronize(self.device)
-        out = dict(reward=rew.cpu().numpy())
+        self._wait()
+        out = dict(reward=self._host(rew))
         if want_grad:
-            out["grad"] = grad.cpu().numpy()
+            out["grad"] = self._host(grad)
         if want_traj:
-            out["traj"] = traj.cpu().numpy()
+            out["traj"] = self._host(traj)
         return out
 
     def reward_batch(self, world_state, weights):
         d = self.desc
-        ws = self._to_dev(world_state).reshape(-1, d.n_cars, 4)
+        ws = self._in("rw_ws", world_state, (-1, d.n_cars, 4))
         B = ws.shape[0]
-        w = self._to_dev(weights)
-        feats = torch.empty((B, d.n_features), dtype=torch.float32, device=self.device)
-        rew = torch.empty((B,), dtype=torch.float32, device=self.device)
+        w = self._in("rw_w", weights, (-1,))
+        feats = self._out("rw_f", (B, d.n_features))
+        rew = self._out("rw_r", (B,))
         self._call(self.lib.ocd_reward_batch, self._h, _ptr(ws), _ptr(w), _ptr(feats), _ptr(rew), B, self._stream())
-        torch.cuda.synchronize(self.device)
-        return feats.cpu().numpy(), rew.cpu().numpy()
+        self._wait()
+        return self._host(feats), self._host(rew)

@@ -21,7 +21,7 @@ def test_bench_json_line():
     d = json.loads(r.stdout)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "cma_generation_ms", "config2",
-              "config4_share8", "config5_share8", "reference_h5", "reference_h6_extra", "collective"):
+              "config4_share8", "config5_share8", "reference_h5", "reference_h6_extra", "reference_h5_x28", "config1", "collective"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["dtype"] == "f32" and d["data"] == "synthetic"
     assert d["vs_baseline"] is None and d["higher_is_better"] is True and d["scaling"] == "weak"
@@ -69,6 +69,12 @@ def test_bench_json_line():
     for rb in (r5, r6):
         assert rb["cma"]["popsize"] == 9 and rb["cma_generation_ms"] > rb["roofline"]["kernel_ms"] * 0.9
         assert rb["cpu_baseline"]["value"] > 0 and rb["cpu_baseline"]["kind"] == "port"
+    # BASELINE config 1: the scalar drop-in API and the object-by-object path, with the CPU oracle beside them
+    c1 = d["config1"]
+    assert c1["episodes"] == 3 and c1["kernel_ms"] <= c1["eval_weights_ms"] < c1["kernel_ms"] + 0.3
+    assert 0.05 < c1["world_step_ms"] < 0.35 and c1["world_steps_timed"] == 45          # (round 4: 0.39 ms per world.step())
+    assert c1["parity"]["eval_weights_cost_bitwise_equal"] and c1["parity"]["world_step_returns_bitwise_equal"]
+    assert c1["cpu_baseline"]["cores"] == 1 and c1["cpu_baseline"]["value"] > 0
     # 28 independent runs of the reference's shape in lockstep: one launch per generation, about the wall time of ONE run
     x28 = d["reference_h5_x28"]
     assert x28["runs"] == 28 and x28["episodes_per_generation"] == 28 * 27 and x28["lockstep"] is True

@@ -22,9 +22,10 @@ def test_oracle_matches_torch_episodes(oracle, case):
     print(case, tec.check(scn, z, rollout_fn, plan_fn))
 
 
-def test_all_ten_episode_fixtures_are_present():
+def test_all_twelve_episode_fixtures_are_present():
     assert tec.cases() == ["finite_horizon_h10", "finite_horizon_h5", "finite_horizon_h6", "local_opt_h10", "local_opt_h5",
-                           "local_opt_h5_extra", "merging_h10", "merging_h5", "replanning_h10", "replanning_h5"]
+                           "local_opt_h5_extra", "merging_h10", "merging_h25", "merging_h5", "replanning_h10", "replanning_h15",
+                           "replanning_h5"]
 
 
 def test_host_mirror_fitness_matches_the_float64_cost(oracle):
@@ -42,20 +43,54 @@ def test_host_mirror_fitness_matches_the_float64_cost(oracle):
         np.testing.assert_allclose(cost[full], z["cost"][full], rtol=1e-4)
 
 
-@pytest.mark.parametrize("case", [c for c in tec.cases() if not c.endswith("h10")])
+@pytest.mark.parametrize("case", tec.cases())
 def test_float64_build_of_the_oracle_follows_the_float64_episodes(case):
-    """The oracle compiled in double (`make -C oracle fp64`: every float a double, constants keep their fp32 values)
-    against the float64 torch episodes: with rounding out of the way on both sides the two restatements agree to 1e-6
-    on EVERY episode of the reference's horizons (measured 3e-7; the residue is fp32(0.1) vs 0.1-style constants) --
-    the fp32-unstable ones included, i.e. the 1e-4 of the float32 comparison is rounding, not a difference of algorithm."""
+    """Rounding out of the way on BOTH sides: the oracle compiled in double (`make -C oracle fp64`: every float a double,
+    constants keep their fp32 values) against torch's float64 run on the same float32 constants (`c32_*`: the
+    reference's traced graph holds float32 numbers for dt, dt ** 2, friction, 0.08 ...; torch_episode._Constants).
+
+    * At the reference's horizons (H = 5, 6) the two agree on EVERY episode (measured ~1e-12).
+    * At H >= 10 a hundred plain-SGD steps amplify even 1e-13 past 1e-3 on some plans (the generator measures that with
+      torch alone: `c32_stable_steps`, the leading steps over which a 1e-13 nudge of the init state stays below 1e-8):
+      every episode must agree on those leading steps, and whole episodes / returns where all T steps are determined.
+    * And with nothing iterated -- the objective and its gradient at the END points of every plan of every control
+      step of every episode (`c32_final_plans`, at the run's own world states) -- the two agree to 1e-9 on EVERY one,
+      at H = 10, 15 and 25: what separates them on the remaining steps is the iteration's sensitivity, not the
+      algorithm (naive_planner.py:33-77 unrolled 10 / 15 / 25 deep, replanning_world.py:24-36 at T = 20)."""
     import oracle_lib
     o64 = oracle_lib.load("fp64")
     scn, z = tec.load(case)
+    d = scn.desc
     w = z["planner_w32"].astype(np.float64)
     inits = z["init_states"].astype(np.float32).astype(np.float64)         # tf.constant(init, dtype=tf.float32)
-    out = o64.rollout(scn.desc, inits, w, want_traj=True)
-    E = out["returns"].shape[0]
-    rerr = np.abs(out["returns"] - z["sample_reward"]) / np.maximum(1e-2, np.abs(z["sample_reward"]))
-    terr = np.abs(out["traj"] - z["states"]).reshape(E, -1).max(axis=1)
-    cerr = np.abs(out["ctrl"] - z["controls"]).reshape(E, -1).max(axis=1)
-    assert rerr.max() <= 1e-6 and terr.max() <= 1e-6 and cerr.max() <= 2e-6, (rerr.max(), terr.max(), cerr.max())
+    out = o64.rollout(d, inits, w, want_traj=True)
+    E, T = out["returns"].shape[0], d.episode_len
+    lead = z["c32_stable_steps"]
+    in_lead = np.arange(T)[None, :] < lead[:, None]
+    cstep = np.abs(out["ctrl"] - z["c32_controls"]).max(axis=2)
+    sstep = np.abs(out["traj"][:, 1:] - z["c32_states"][:, 1:]).reshape(E, T, -1).max(axis=2)
+    full = lead == T
+    rerr = np.abs(out["returns"] - z["c32_sample_reward"]) / np.maximum(1e-2, np.abs(z["c32_sample_reward"]))
+    print(case, f"determined: {int(full.sum())}/{E} whole episodes, {int(in_lead.sum())}/{E * T} leading steps; worst ctrl "
+          f"{cstep[in_lead].max():.1e} state {sstep[in_lead].max():.1e} return {rerr[full].max() if full.any() else float('nan'):.1e}; "
+          f"all episodes within 1e-6: {float(((rerr <= 1e-6) & (cstep.max(axis=1) <= 2e-6)).mean()):.2f}")
+    assert cstep[in_lead].max() <= 2e-6 and sstep[in_lead].max() <= 1e-6
+    assert not full.any() or rerr[full].max() <= 1e-6
+    if d.horizon <= 6:
+        assert full.all()                                                  # the reference's horizons: every episode
+    else:
+        assert in_lead.sum() >= 0.3 * E * T
+    if "c32_final_plans" in z.files:                                       # H >= 10: objective + gradient, every plan
+        N, S = inits.shape[0], d.n_samples
+        other = scn.other_plans()
+        worst_r = worst_g = 0.0
+        for e in range(E):
+            we = w[e // (N * S)]
+            for t in range(T):
+                for k in range(d.n_ctrl_inits):
+                    r, g, _ = o64.mpc_reward(d, z["c32_past"][e, t], we, z["c32_final_plans"][e, t, k], other)
+                    loss, gt = z["c32_final_losses"][e, t, k], z["c32_final_grad"][e, t, k]
+                    worst_r = max(worst_r, abs(-float(r) - loss) / max(1.0, abs(loss)))
+                    worst_g = max(worst_g, float(np.abs(g - gt).max()) / max(1.0, float(np.abs(gt).max())))
+        print(case, f"objective / gradient at {E * T * d.n_ctrl_inits} plan end points: worst {worst_r:.1e} / {worst_g:.1e}")
+        assert worst_r <= 1e-9 and worst_g <= 1e-9

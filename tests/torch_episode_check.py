@@ -17,7 +17,10 @@ What is compared, and how tightly (fp32 implementation against a float64 run of 
                             at the fixture's own world states (ocd_plan_batch on `past`)
 "fp32-stable" is decided by the generator with torch alone (the same episodes in torch float32 stay within 2e-5 of
 the float64 run); the checker asserts that most episodes are stable and prints the fraction of ALL episodes within
-tolerance.
+tolerance.  Beyond whole episodes: `fp32_stable_steps[e]` leading control steps of EVERY episode follow the float64 run
+in torch's own float32 run -- on those steps the controls and the world states are held to 1e-4 as well, which is what
+carries the check to BASELINE's horizons (H = 10, 15, 25), where a hundred SGD steps amplify rounding and few whole
+episodes are fp32-stable.
 """
 import glob
 import os
@@ -72,7 +75,7 @@ def check(scn, z, rollout_fn, plan_fn=None):
     stable = z["stable"]
     # at the reference's horizons nearly every episode is fp32-stable; at BASELINE's scaled-up H = 10 a hundred SGD
     # steps amplify rounding and torch's own float32 run leaves its float64 run on most episodes
-    need = 0.75 if d.horizon <= 6 else 0.25
+    need = 0.75 if d.horizon <= 6 else (0.25 if d.horizon <= 10 else 0.0)
     assert stable.mean() >= need, f"only {stable.sum()} of {E} episodes are fp32-stable in torch itself"
     rerr = np.abs(ret - z["sample_reward"]) / np.maximum(1e-2, np.abs(z["sample_reward"]))
     terr = np.abs(traj - z["states"]).reshape(E, -1).max(axis=1)
@@ -80,6 +83,14 @@ def check(scn, z, rollout_fn, plan_fn=None):
     ok = (rerr <= 1e-4) & (terr <= 1e-4) & (cerr <= 1e-4)
     assert ok[stable].all(), dict(returns=rerr[stable].max(), traj=terr[stable].max(), ctrl=cerr[stable].max(),
                                   episodes=np.nonzero(stable & ~ok)[0])
+    # every episode, as far as torch's own float32 run follows its float64 run: controls and states of those steps
+    lead = z["fp32_stable_steps"]
+    assert np.array_equal(lead == T, stable) or d.horizon > 6        # (whole-episode stability also looks at the return)
+    in_lead = np.arange(T)[None, :] < lead[:, None]                    # [E, T]
+    cstep = np.abs(ctrl - z["controls"]).max(axis=2)
+    sstep = np.abs(traj[:, 1:] - z["states"][:, 1:]).reshape(E, T, -1).max(axis=2)
+    assert in_lead.sum() >= (0.9 if d.horizon <= 6 else 0.3) * E * T, f"torch's fp32 run follows only {in_lead.sum()} of {E * T} steps"
+    assert cstep[in_lead].max() <= 1e-4 and sstep[in_lead].max() <= 1e-4, (cstep[in_lead].max(), sstep[in_lead].max())
     # the state every step scores and plans from: after a teleport the removed car sits at (10, 0, 0, 0)
     if d.teleport_step > 0:
         t = d.teleport_step - 1
@@ -94,15 +105,21 @@ def check(scn, z, rollout_fn, plan_fn=None):
     full = st_pn.all(axis=1)
     if full.any():
         assert (np.abs(cost - z["cost"])[full] <= 1e-4 * np.maximum(1.0, np.abs(z["cost"][full]))).all()
+    worst = lambda a: float(a[stable].max()) if stable.any() else float("nan")  # noqa: E731
     summary = dict(episodes=E, stable=int(stable.sum()), within_tol_all=float(ok.mean()),
-                   worst_return=float(rerr[stable].max()), worst_traj=float(terr[stable].max()),
-                   worst_ctrl=float(cerr[stable].max()))
+                   worst_return=worst(rerr), worst_traj=worst(terr), worst_ctrl=worst(cerr),
+                   leading_steps=f"{int(in_lead.sum())}/{E * T}", worst_leading_ctrl=float(cstep[in_lead].max()),
+                   worst_leading_state=float(sstep[in_lead].max()))
     # --- which control initialisation generate_plan keeps, at the fixture's own world states ----------------------
     if plan_fn is not None:
         losses_gap = z["margin"]                                    # [E, T] best-to-second gap of the float64 losses
         clear = stable[:, None] & (losses_gap > 1e-3)
         ee, tt = np.nonzero(clear)
-        assert len(ee) >= (0.5 if d.horizon <= 6 else 0.15) * E * T, f"only {len(ee)} of {E * T} plans have a decided argmin"
+        assert len(ee) >= (0.5 if d.horizon <= 6 else (0.15 if d.horizon <= 10 else 0.0)) * E * T, \
+            f"only {len(ee)} of {E * T} plans have a decided argmin"
+        # ... and on every leading step of every episode (there the fp32 run keeps the float64 run's initialisation)
+        clear = clear | (in_lead & (losses_gap > 1e-3))
+        ee, tt = np.nonzero(clear)
         ws = z["past"][ee, tt].astype(np.float32)
         wrow = np.repeat(w32, N * S, axis=0)[ee]
         got = np.asarray(plan_fn(ws, wrow)).astype(np.int32)
