@@ -55,20 +55,32 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak fp32 vector
 
 
-def pmc_record(key, n_episodes):
+def pmc_record(key, n_episodes, kernel_name):
     """Counters of the episode kernel from the committed rocprofv3 PMC passes (profiles/pmc_counters.json:
     separate --pmc runs of this same command; FETCH_SIZE / WRITE_SIZE in KiB per launch -- dword-granular
     accesses, so the guide's 2x FETCH correction for wide streaming reads does not apply -- and the SQ
-    counters per launch).  None when no profile of this workload is committed."""
+    counters per launch).  Returns (record, None), or (None, why): a record is replayed only beside THE kernel it was
+    taken from -- same demangled name as the launch it annotates, same episodes per launch, and kernels built from the
+    same sources (abi.kernel_source_sha) as the profiled ones."""
+    from l4dc_mpc_ocd_amd import abi
     path = os.path.join(ROOT, "profiles", "pmc_counters.json")
     try:
         with open(path) as f:
-            rec = json.load(f).get(key)
+            allrec = json.load(f)
     except (OSError, ValueError):
-        return None
-    if not rec or rec.get("episodes_per_launch") != n_episodes:
-        return None
-    return rec
+        return None, "no profiles/pmc_counters.json"
+    rec = allrec.get(key)
+    if not rec:
+        return None, f"no profile of {key} is committed"
+    if rec.get("episodes_per_launch") != n_episodes:
+        return None, f"the profile of {key} has {rec.get('episodes_per_launch')} episodes per launch, this launch {n_episodes}"
+    if rec.get("kernel_name") != kernel_name:
+        return None, f"the profile of {key} is of {rec.get('kernel_name')}, this launch runs {kernel_name}"
+    if allrec.get("_kernel_source_sha") != abi.kernel_source_sha():
+        return None, (f"stale: the profile was taken on kernel sources {allrec.get('_kernel_source_sha')} (commit "
+                      f"{allrec.get('_git_commit')}), this tree has {abi.kernel_source_sha()}")
+    rec = dict(rec, git_commit=allrec.get("_git_commit"), kernel_source_sha=allrec.get("_kernel_source_sha"))
+    return rec, None
 
 
 PMC_SOURCE = ("profiles/pmc_counters.json: rocprofv3 --pmc passes of this command on the builder's box "
@@ -657,9 +669,19 @@ def main():
         ach_gbs = n_local * nbytes / (kern_ms * 1e-3) / 1e9
         ach_tf = n_local * flops / (kern_ms * 1e-3) / 1e12
         n_split = max(1, round(P * N * S / max(n_local, 1)))
-        pmc = pmc_record(f"cfg{cfg_index}_share{n_split}" if per_gpu_only else
-                         (cfg_index if isinstance(cfg_index, str) else f"cfg{cfg_index}"), n_local)
+        from l4dc_mpc_ocd_amd import abi as _abi
+        mangled = _abi.planner_kernel_name(d, launch)
+        pmc, pmc_why = pmc_record(f"cfg{cfg_index}_share{n_split}" if per_gpu_only else
+                                  (cfg_index if isinstance(cfg_index, str) else f"cfg{cfg_index}"), n_local, mangled)
         traffic = (pmc["fetch_kib"] + pmc["write_kib"]) * 1024.0 if pmc else None
+        rocprof = {"replayed": False, "why": pmc_why}
+        if pmc:
+            rocprof = {"replayed": True, "profile": pmc.get("profile"), "git_commit": pmc["git_commit"],
+                       "kernel_source_sha": pmc["kernel_source_sha"], "kernel_name": pmc["kernel_name"],
+                       "kernel_avg_ms": pmc["kernel_avg_us"] / 1e3, "kernel_calls": pmc["kernel_calls"],
+                       "kernel_steady_avg_ms": (pmc.get("kernel_steady_avg_us") or pmc["kernel_avg_us"]) / 1e3,
+                       "rule": "the profile's steady-state kernel average (later half of its dispatches) must not exceed this "
+                               "line's ms_per_step beyond box-to-box variation (1.5 %): tests/test_gpu_bench_contract.py"}
         profiled = None
         valu = {"achieved": ach_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / VALU_PEAK_TFLOPS,
                 "algorithmic_flops_per_episode": flops,
@@ -684,7 +706,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": PMC_SOURCE if pmc else None,
-                         "kernel": kernel_name, "kernel_ms": kern_ms, "launch": launch,
+                         "kernel": kernel_name, "kernel_symbol": mangled, "kernel_ms": kern_ms, "launch": launch,
+                         "rocprof": rocprof,
                          "algorithmic_bytes_per_episode": nbytes,
                          # what actually bounds the kernel: fp32 vector issue -- algorithmic flops per
                          # launch / kernel_ms against the fp32 vector peak (the same numbers as `valu`)

@@ -167,6 +167,37 @@ def load_hip_library(path: Optional[str] = None) -> C.CDLL:
     return lib
 
 
+def kernel_source_sha() -> str:
+    """sha256 (first 16 hex digits) over the sources the device code is built from -- csrc/*.hip, csrc/*.h and
+    include/ocd.h, in name order: the identity of the kernels.  Profiles record it (tools/rocprof_summary.py) and
+    bench.py replays a profile's counters only beside kernels built from the same sources."""
+    import glob
+    import hashlib
+    csrc = os.path.join(_PKG_DIR, "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")))
+    files.append(os.path.join(os.path.dirname(_PKG_DIR), "include", "ocd.h"))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def planner_kernel_name(desc, launch: dict) -> str:
+    """The demangled name of the planner kernel a launch record (decode_launch) stands for, as rocprofv3 prints it:
+    ocd::mpc_kernel<HT, NO, L, V, LEAF, LAT> / ocd::mpc_chunk_kernel<HT, NO, L, S, LAT, OCC3> (csrc/ocd_kernels.hip,
+    csrc/ocd_chunk_kernel.hip)."""
+    b = lambda v: "true" if v else "false"  # noqa: E731
+    no = desc.n_cars - 1
+    lanes = desc.n_lanes if desc.reward_kind == OCD_REWARD_LANE_FEATURES else (0 if desc.reward_kind == OCD_REWARD_TARGET_SPEED else -1)
+    ht, build = launch["specialised_horizon"], launch["build_wavefronts_per_simd"]
+    if launch["scan_mode"] == 4:
+        return f"void ocd::mpc_chunk_kernel<{ht}, {no}, {lanes}, {launch['chunk']}, {b(build == 1)}, {b(build >= 3)}>(ocd::KernelParams)"
+    v = {1: 0, 2: 1, 3: 2}.get(launch["scan_mode"], 0)
+    return f"void ocd::mpc_kernel<{ht}, {no}, {lanes}, {v}, {b(launch['terminal_value'])}, {b(build == 1)}>(ocd::KernelParams)"
+
+
 def check(lib: C.CDLL, status: int) -> None:
     if status != OCD_OK:
         msg = lib.ocd_last_error()

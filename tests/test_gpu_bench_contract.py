@@ -88,5 +88,14 @@ def test_bench_json_line():
         par = blk["parity"]
         assert par["episodes_checked"] >= n_min and par["bitwise_equal"] == par["episodes_checked"] == par["within_1e-4_rel"]
         assert par["argmin_flips"] == 0 and par["plan_steps_checked"] >= par["episodes_checked"] * 10 and par["ranks"] == 1
+    # counters and the rocprof kernel average are replayed only from a profile of THIS kernel built from THESE sources; then
+    # the profile's steady-state kernel average must agree with the live step (it may not exceed it beyond box variation)
+    rp = rf["rocprof"]
+    assert rf["kernel_symbol"] == "void ocd::mpc_kernel<10, 1, 3, 2, false, true>(ocd::KernelParams)"
+    if rp["replayed"]:
+        assert rp["kernel_name"] == rf["kernel_symbol"] and rp["kernel_steady_avg_ms"] <= d["ms_per_step"] * 1.015, rp
+        assert abs(rp["kernel_steady_avg_ms"] - rf["kernel_ms"]) <= 0.03 * rf["kernel_ms"], (rp, rf["kernel_ms"])
+    else:
+        assert rf["traffic"] is None and rp["why"]
     # the parsed roofline object names the bound that binds (fp32 vector issue) beside the contract's HBM figures
     assert rf["binding"] == "valu" and abs(rf["binding_frac"] - d["valu"]["frac"]) < 1e-12 and 0.05 < rf["binding_frac"] < 1

@@ -2,7 +2,9 @@
 # rocprofv3 evidence for profiles/: per BASELINE config, one kernel-trace/stats run and three PMC passes
 # (FETCH_SIZE, WRITE_SIZE, SQ_*) of the SAME bench.py command, each in its own run (gpurun refuses
 # --pmc combined with the trace domains other than --kernel-trace).  Run ON THE GPU BOX from the repo root:
-#     bash tools/profile_round.sh r04 "2 3 4 5 4s 5s reference_h5 reference_h6_extra"
+#     OCD_GIT_COMMIT=<hash of the tree being profiled> bash tools/profile_round.sh r05 "2 3 4 5 4s 5s reference_h5 reference_h6_extra"
+# (the GPU box holds no .git: the commit travels in the environment; profiles/pmc_counters.json records it together with
+#  the hash of the kernel sources, and bench.py replays the counters only beside kernels built from those sources)
 # A workload token is a BASELINE config index, or <index>s = the share of rank 0 of an 8-way strong split of that
 # config run on this one GPU (bench.py --emulate-rank 0/8): 4s = 2 048 episodes at H=15, 5s = 4 096 at H=25.
 # Writes rocpd databases under gpurun_out/prof_<round>/ (scratch) and the condensed summaries

@@ -45,6 +45,12 @@ def counters_json(round_name, out_dir):
     rec = {"_source": f"profiles/{round_name}_cfg<N>_rocprofv3.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* "
                       "(separate passes, --kernel-trace only) of `bench.py --config N [--emulate-rank 0/8] --no-extras`, kernels ocd::mpc_kernel / ocd::mpc_chunk_kernel (cfgN_share8: rank 0's block of an 8-way split); "
                       "FETCH/WRITE in KiB per launch as counted (dword-granular accesses), SQ_* per launch (quad-cycles)"}
+    # which tree the profiled kernels were built from: the commit (given by the caller: the GPU box holds no .git) and
+    # the hash of the kernel sources, which bench.py recomputes before it replays any of these numbers
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from l4dc_mpc_ocd_amd import abi
+    rec["_git_commit"] = os.environ.get("OCD_GIT_COMMIT", "unknown")
+    rec["_kernel_source_sha"] = abi.kernel_source_sha()
     for d in sorted(glob.glob(os.path.join(out_dir, "c*_sq"))):
         cfg = re.search(r"c(\d+s?|reference_\w+?)_sq$", d).group(1)   # "4" = the whole config, "4s" = one of 8 GPUs' share
         vals = {}
@@ -63,6 +69,12 @@ def counters_json(round_name, out_dir):
                     try:
                         for name, calls, avg in cur.execute("select name, total_calls, average from top_kernels where name like '%mpc_%kernel%'"):
                             vals["kernel_avg_us"], vals["kernel_calls"], vals["kernel_name"] = avg, calls, name
+                        # steady state: the later half of the dispatches (the first launches of a cold process run on
+                        # clocks that are still rising -- bench.py's own kernel_ms is taken after its warm-up as well)
+                        durs = [r[0] for r in cur.execute("select duration from kernels where name like '%mpc_%kernel%' order by start")]
+                        if durs:
+                            tail = durs[len(durs) // 2:]
+                            vals["kernel_steady_avg_us"] = sum(tail) / len(tail) / 1e3
                     except sqlite3.Error:
                         pass
         log = os.path.join(out_dir, f"c{cfg}_stats.log")
@@ -77,7 +89,9 @@ def counters_json(round_name, out_dir):
             "sq_insts_valu": vals.get("SQ_INSTS_VALU"), "sq_active_inst_valu": vals.get("SQ_ACTIVE_INST_VALU"),
             "sq_active_inst_any": vals.get("SQ_ACTIVE_INST_ANY"), "sq_wait_any": vals.get("SQ_WAIT_ANY"),
             "sq_insts_lds": vals.get("SQ_INSTS_LDS"), "kernel_avg_us": vals.get("kernel_avg_us"),
+            "kernel_steady_avg_us": vals.get("kernel_steady_avg_us"),
             "kernel_calls": vals.get("kernel_calls"), "kernel_name": vals.get("kernel_name"),
+            "profile": f"profiles/{round_name}_{key if key.startswith('reference_') else key}_rocprofv3.txt",
             "grid_size": vals.get("grid_size"), "workgroup_size": vals.get("workgroup_size")}
     print(json.dumps(rec, indent=1))
 
