@@ -102,7 +102,8 @@ class MPC_ORD:
         self.save_path = save_path
         self.designer_weights = car.weights / np.linalg.norm(car.weights)
         self.weight_dim = len(car.weights)
-        self.history = list2()
+        self._history = list2()
+        self._history_chunks = []        # (weights [G, P, D], costs [G, P]) blocks of the native loops, not yet in the list
         self.iter = 0
         self.should_save_history = False
         self.done = False
@@ -115,6 +116,23 @@ class MPC_ORD:
         self._overlap_hooks = []
         self.n_nonfinite = []            # per eval_population call: costs that came back NaN or +-inf
         self.max_nan_resamples = 10      # rounds of pycma-style rejection sampling per generation
+
+    # the (weights, reward) list of the reference (mpc_ord.py:27,146).  The native generation loops hand their rows over
+    # as arrays, many generations at a time; they become list entries when somebody looks (len, iteration, pickling) --
+    # 64 tuples per generation built inside the loop cost 35 us of a 1.5 ms generation
+    @property
+    def history(self):
+        if self._history_chunks:
+            chunks, self._history_chunks = self._history_chunks, []
+            for W, cost in chunks:
+                for g in range(W.shape[0]):
+                    self._history.extend(zip(W[g], -cost[g]))
+        return self._history
+
+    @history.setter
+    def history(self, value):
+        self._history_chunks = []
+        self._history = value
 
     # ------------------------------------------------------------------ GPU plumbing
     def _engine(self):
@@ -176,7 +194,7 @@ class MPC_ORD:
         optimize_cmaes this runs while the NEXT generation's kernel does; everywhere else immediately."""
         if self._pending_history is not None:
             Wn, cost = self._pending_history
-            self.history.extend(zip(Wn, -cost))
+            self.history.extend(zip(Wn, -cost))                    # (the property first lists what the native loops left)
             self._pending_history = None
 
     def _tick(self, name, t0):
@@ -410,10 +428,10 @@ class MPC_ORD:
             toggles = hasattr(self.world, "unlucky_car_idx") and (E % 2)
 
             def book(g0, g1):                                      # generations [g0, g1) of this call's buffers
-                for g in range(g0, g1):
-                    self.history.extend(zip(hist_w[g].copy(), -hist_c[g]))
-                    self.iter += P
-                    if toggles:                                    # world.reset() side effects, as _returns keeps them
+                if g1 > g0:
+                    self._history_chunks.append((hist_w[g0:g1].copy(), hist_c[g0:g1].copy()))   # (mpc_ord.py:146, lazily)
+                    self.iter += P * (g1 - g0)
+                    if toggles and (g1 - g0) % 2:                  # world.reset() side effects, as _returns keeps them
                         self.world.unlucky_car_idx = 2 if self.world.unlucky_car_idx == 1 else 1
 
             while True:
@@ -619,18 +637,20 @@ def optimize_cmaes_lockstep(ords, seeds, sigma0s, popsize=None, maxiter=None, ma
                 if st != 0:
                     raise RuntimeError(f"ocd_cma_run_many -> {st}: {eng.lib.ocd_last_error().decode()}")
                 G = int(done.value)
-                for g in range(G):
-                    for r in np.nonzero(evaluated[g])[0]:
-                        o, p0, lam = ords[r], int(run_p0[r]), int(lams[r])
-                        o.history.extend(zip(hist_w[g, p0:p0 + lam].copy(), -hist_c[g, p0:p0 + lam]))   # mpc_ord.py:146
-                        o.iter += lam
-                        o.generation_seconds.append(float(secs[g, 0]))
-                        if not (g == G - 1 and pending[r]):
-                            o.n_nonfinite.append(int(nonf[g, r]))
-                    res.generation_seconds.append(float(secs[g, 0]))
-                    res.episodes_per_generation.append(int(launched[g]))
-                    for k, name in enumerate(names):
-                        res.host_split.setdefault(name, []).append(float(secs[g, 1 + k]))
+                for r in range(R):                                     # one block per run and native call (mpc_ord.py:146, lazily)
+                    took = np.nonzero(evaluated[:G, r])[0]
+                    if took.size == 0:
+                        continue
+                    o, p0, lam = ords[r], int(run_p0[r]), int(lams[r])
+                    o._history_chunks.append((hist_w[took, p0:p0 + lam], hist_c[took, p0:p0 + lam]))    # (fancy index: copies)
+                    o.iter += lam * int(took.size)
+                    o.generation_seconds.extend(secs[took, 0].tolist())
+                    told = took[:-1] if pending[r] else took            # (a pending generation is counted after its redraw)
+                    o.n_nonfinite.extend(int(v) for v in nonf[told, r])
+                res.generation_seconds.extend(secs[:G, 0].tolist())
+                res.episodes_per_generation.extend(int(v) for v in launched[:G])
+                for k, name in enumerate(names):
+                    res.host_split.setdefault(name, []).extend(secs[:G, 1 + k].tolist())
                 for r in np.nonzero(pending)[0]:                       # pycma's rejection sampling, as the run alone does it
                     o, es = ords[r], ess[r]
                     f = es._f.copy()

@@ -42,6 +42,10 @@ where the 1e-8 between fp32(0.1) and 0.1 is amplified past it:
                     follows it within 1e-8 (controls and states) for this many leading control steps; = T where the
                     whole episode does.  A hundred plain-SGD steps amplify 1e-13 past 1e-3 on some plans at H >= 10:
                     beyond that step no second float64 implementation can be expected to land on the same numbers.
+  c32_nudge_step [E,T]   the raw figure behind it: how far (controls / states, max) the 1e-13 nudge moved each step, i.e.
+                    1e-13 x the amplification of the iteration up to that step.  float32 implementations are compared on
+                    the leading steps with amplification <= 100 (<= 1e-11 here): there rounding noise of 1e-7 stays
+                    below 1e-4 for any implementation, not just for torch's own float32 run.
   c32_final_plans [E,T,K,H,2], c32_final_losses [E,T,K], c32_final_grad [E,T,K,H,2]   (H >= 10 cases) what
                     generate_plan ended on for every control initialisation at every control step, with dR/du there:
                     single objective + gradient evaluations at the run's own world states (c32_past) -- nothing
@@ -148,6 +152,7 @@ def make(case):
         if k in c32:
             out["c32_" + k] = c32[k]
     out["c32_stable_steps"] = stable_steps
+    out["c32_nudge_step"] = dstep                      # [E, T]: how far the 1e-13 nudge moved each step (amplification x 1e-13)
     path = os.path.join(HERE, f"torch_episode_{case}.npz")
     np.savez_compressed(path, **out)
     print(f"{os.path.basename(path)}: {E} episodes, fp32-stable {int(stable.sum())}/{E}, returns "

@@ -9,7 +9,7 @@ most independent check the HIP path can be given: tests/test_gpu_torch_fixtures.
 ocd_mpc_reward_batch and ocd_plan_batch with these values (tolerances there: fp32 kernels vs float64 autograd),
 tests/test_torch_fixtures.py does the same for the oracle on the CPU.
 
-Per (scenario, H in {5, 10}) fixture, B = 32 world states -- the first 8 inside a scripted car's collision bump,
+Per (scenario, H) fixture -- H in {5, 10} for the four scenarios, replanning H = 15 and merging H = 25 (BASELINE configs 4 / 5) -- B = 32 world states -- the first 8 inside a scripted car's collision bump,
 the next 8 beyond the fence threshold, every 5th control row beyond the clip range:
     world_states [B,C,4] f32, weights [B,D] f32 (normalised candidates), controls [B,H,2] f32, other_plans
     features [B,D] f64, R [B] f64, grad [B,H,2] f64, traj [B,H,4] f64          (objective at the given controls)
@@ -20,7 +20,7 @@ the next 8 beyond the fence threshold, every 5th control row beyond the clip ran
         where torch's own fp32 run leaves the fp64 one (steep bumps: the iteration amplifies rounding), no fp32
         implementation can be held to it.  Decided by torch alone, not by the code under test.
 
-usage: python tests/golden/make_torch_fixtures.py      (rewrites the eight files; deterministic)
+usage: python tests/golden/make_torch_fixtures.py [scenario:H ...]     (rewrites the ten files, or the named ones; deterministic)
 """
 import os
 import sys
@@ -98,10 +98,19 @@ def make(name, H, seed):
           f"fp32-stable SGD pairs {int(np.sum(stable))}/{np.size(stable)}")
 
 
+# (scenario, H) -> seed.  H = 5 / 10: every scenario; H = 15 / 25 (round 5): BASELINE configs 4 / 5's own horizons, on their
+# scenarios -- naive_planner.py:33-77 unrolled 15 / 25 deep, objective and gradient against float64 autograd
+CASES = {(name, H): 4000 + 10 * i + H for i, name in enumerate(("finite_horizon", "local_opt", "replanning", "merging"))
+         for H in (5, 10)}
+CASES[("replanning", 15)] = 4035
+CASES[("merging", 25)] = 4055
+
+
 def main():
-    for i, name in enumerate(("finite_horizon", "local_opt", "replanning", "merging")):
-        for H in (5, 10):
-            make(name, H, seed=4000 + 10 * i + H)
+    want = [tuple(a.split(":")) for a in sys.argv[1:]]
+    for (name, H), seed in CASES.items():
+        if not want or (name, str(H)) in want:
+            make(name, H, seed=seed)
 
 
 if __name__ == "__main__":

@@ -27,5 +27,5 @@ def test_oracle_matches_torch_fixture(oracle, name, H):
     print(name, H, worst)
 
 
-def test_all_eight_fixtures_are_present():
-    assert len(tfc.fixtures()) == 8
+def test_all_ten_fixtures_are_present():
+    assert len(tfc.fixtures()) == 10 and ("replanning", 15) in tfc.fixtures() and ("merging", 25) in tfc.fixtures()

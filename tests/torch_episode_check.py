@@ -86,11 +86,20 @@ def check(scn, z, rollout_fn, plan_fn=None):
     # every episode, as far as torch's own float32 run follows its float64 run: controls and states of those steps
     lead = z["fp32_stable_steps"]
     assert np.array_equal(lead == T, stable) or d.horizon > 6        # (whole-episode stability also looks at the return)
-    in_lead = np.arange(T)[None, :] < lead[:, None]                    # [E, T]
+    # ... and only while the iteration's amplification stays below ~100 (the float64 run with every ego init state moved
+    # by 1e-13 stays within 1e-11, c32_nudge_step): there ANY float32 implementation's rounding noise stays below
+    # 1e-4 -- torch's float32 run alone can land close to the float64 one by luck on a plan that amplifies by 1e4
+    tame = np.maximum.accumulate(z["c32_nudge_step"], axis=1) <= 1e-11
+    in_lead = (np.arange(T)[None, :] < lead[:, None]) & tame         # [E, T]
     cstep = np.abs(ctrl - z["controls"]).max(axis=2)
     sstep = np.abs(traj[:, 1:] - z["states"][:, 1:]).reshape(E, T, -1).max(axis=2)
-    assert in_lead.sum() >= (0.9 if d.horizon <= 6 else 0.3) * E * T, f"torch's fp32 run follows only {in_lead.sum()} of {E * T} steps"
-    assert cstep[in_lead].max() <= 1e-4 and sstep[in_lead].max() <= 1e-4, (cstep[in_lead].max(), sstep[in_lead].max())
+    # (H = 15 / 25: already the FIRST plan of an episode amplifies 1e-13 past 1e-8 in torch itself -- no leading step is
+    #  determined; those fixtures carry the scenario constants, the removed cars and the plan end points of the float64
+    #  test, and the planner-level fixtures tests/golden/torch_<scenario>_h<H>.npz hold R and dR/du at these horizons)
+    min_lead = 0.9 if d.horizon <= 6 else (0.15 if d.horizon <= 10 else 0.0)
+    assert in_lead.sum() >= min_lead * E * T, f"torch's fp32 run follows only {in_lead.sum()} of {E * T} steps"
+    if in_lead.any():
+        assert cstep[in_lead].max() <= 1e-4 and sstep[in_lead].max() <= 1e-4, (cstep[in_lead].max(), sstep[in_lead].max())
     # the state every step scores and plans from: after a teleport the removed car sits at (10, 0, 0, 0)
     if d.teleport_step > 0:
         t = d.teleport_step - 1
@@ -100,7 +109,7 @@ def check(scn, z, rollout_fn, plan_fn=None):
     dr = ret.reshape(P, N, S).sum(axis=2)
     st_pn = stable.reshape(P, N, S).all(axis=2)
     derr = np.abs(dr - z["designer_reward"]) / np.maximum(1e-2, np.abs(z["designer_reward"]))
-    assert derr[st_pn].max() <= 1e-4
+    assert not st_pn.any() or derr[st_pn].max() <= 1e-4
     cost = -dr.sum(axis=1) / S
     full = st_pn.all(axis=1)
     if full.any():
@@ -108,8 +117,9 @@ def check(scn, z, rollout_fn, plan_fn=None):
     worst = lambda a: float(a[stable].max()) if stable.any() else float("nan")  # noqa: E731
     summary = dict(episodes=E, stable=int(stable.sum()), within_tol_all=float(ok.mean()),
                    worst_return=worst(rerr), worst_traj=worst(terr), worst_ctrl=worst(cerr),
-                   leading_steps=f"{int(in_lead.sum())}/{E * T}", worst_leading_ctrl=float(cstep[in_lead].max()),
-                   worst_leading_state=float(sstep[in_lead].max()))
+                   leading_steps=f"{int(in_lead.sum())}/{E * T}",
+                   worst_leading_ctrl=float(cstep[in_lead].max()) if in_lead.any() else float("nan"),
+                   worst_leading_state=float(sstep[in_lead].max()) if in_lead.any() else float("nan"))
     # --- which control initialisation generate_plan keeps, at the fixture's own world states ----------------------
     if plan_fn is not None:
         losses_gap = z["margin"]                                    # [E, T] best-to-second gap of the float64 losses
@@ -120,6 +130,9 @@ def check(scn, z, rollout_fn, plan_fn=None):
         # ... and on every leading step of every episode (there the fp32 run keeps the float64 run's initialisation)
         clear = clear | (in_lead & (losses_gap > 1e-3))
         ee, tt = np.nonzero(clear)
+        if len(ee) == 0:
+            summary["chosen_checked"] = 0
+            return summary
         ws = z["past"][ee, tt].astype(np.float32)
         wrow = np.repeat(w32, N * S, axis=0)[ee]
         got = np.asarray(plan_fn(ws, wrow)).astype(np.int32)

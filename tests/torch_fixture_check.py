@@ -78,7 +78,9 @@ def check(scn, z, reward_fn, objective_fn, plan_fn):
     # (state, initialisation) pairs whose 25-step SGD run torch itself reproduces in float32 (sgd_stable, decided by
     # the generator without the code under test): end points within tolerance; the others amplify rounding
     st = z["sgd_stable"]
-    assert st.mean() >= 0.8, st
+    # (H = 15 / 25, round 5: even 25 SGD steps amplify rounding on most pairs -- torch's own float32 run keeps about a
+    #  third of them; the non-iterated R / dR/du above is what those horizons are held to on EVERY state)
+    assert st.mean() >= (0.8 if scn.desc.horizon <= 10 else 0.25), st
     lerr = np.abs(out["all_losses"] - z["sgd_losses"]) / np.maximum(1e-2, np.abs(z["sgd_losses"]))
     perr = np.abs(out["all_plans"] - z["sgd_plans"]).reshape(st.shape + (-1,)).max(axis=2)
     assert lerr[st].max() <= 1e-4, lerr
