@@ -27,6 +27,8 @@ typedef const char *(*fn_last_error)(void);
 typedef int32_t (*fn_scenario_create)(const ocd_scenario_desc *, ocd_scenario **);
 typedef void (*fn_scenario_destroy)(ocd_scenario *);
 typedef int32_t (*fn_rollout)(const ocd_scenario *, const float *, const float *, int64_t, int64_t, int64_t, int64_t, float *, float *, float *, void *);
+typedef int32_t (*fn_rollout_indexed)(const ocd_scenario *, const float *, int64_t, const float *, int64_t, const int32_t *, int64_t,
+                                      float *, float *, float *, void *);
 typedef int32_t (*fn_sync)(void *);
 typedef int32_t (*fn_cma_create)(int32_t, const double *, double, int32_t, uint32_t, ocd_cma **);
 typedef void (*fn_cma_destroy)(ocd_cma *);
@@ -76,6 +78,7 @@ int main(int argc, char **argv)
     SYM(hip, fn_scenario_create, ocd_scenario_create)
     SYM(hip, fn_scenario_destroy, ocd_scenario_destroy)
     SYM(hip, fn_rollout, ocd_rollout_episodes)
+    SYM(hip, fn_rollout_indexed, ocd_rollout_indexed)
     SYM(hip, fn_sync, ocd_stream_synchronize)
     SYM(cma, fn_cma_create, ocd_cma_create)
     SYM(cma, fn_cma_destroy, ocd_cma_destroy)
@@ -129,6 +132,21 @@ int main(int argc, char **argv)
     printf("returns");
     for (int i = 0; i < 6; ++i) printf(" %.9g", ret[i]);
     printf("\n");
+    /* the same six episodes as rows of an index, in reverse order (ocd_rollout_indexed: independent populations in one
+     * launch, the reference's Pool over init groups, run_mpc_ord.py:83-90): bit for bit the flat call's returns */
+    {
+        int32_t idx[6][3], *idx_pin;
+        float back[6];
+        for (int e = 0; e < 6; ++e) { idx[e][0] = (5 - e) / 3; idx[e][1] = (5 - e) % 3; idx[e][2] = 5 - e; }
+        if (hipHostMalloc((void **)&idx_pin, sizeof idx, 0)) return 1;
+        memcpy(idx_pin, idx, sizeof idx);
+        if (ocd_rollout_indexed(scn, init_dev, 3, w_dev, 2, idx_pin, 6, ret_dev, NULL, NULL, NULL) != OCD_OK) { fprintf(stderr, "indexed rollout: %s\n", ocd_last_error()); return 1; }
+        if (ocd_stream_synchronize(NULL) != OCD_OK) return 1;
+        hipMemcpy(back, ret_dev, sizeof back, 2);
+        for (int e = 0; e < 6; ++e)
+            if (memcmp(&back[e], &ret[5 - e], sizeof(float))) { fprintf(stderr, "indexed episode %d differs from the flat call\n", e); return 1; }
+        printf("indexed rollout equals the flat call on 6 episodes\n");
+    }
     /* one native CMA-ES generation: population 4, the launch and the wait as function pointers, pinned buffers */
     ocd_cma *es = NULL;
     const double x0[7] = {-0.0624, 0, 0, 0, -0.0749, -0.6244, -0.6244};
@@ -136,14 +154,14 @@ int main(int argc, char **argv)
     float *w_pin, *ret_pin;
     if (hipHostMalloc((void **)&w_pin, 4 * 7 * sizeof(float), 0) || hipHostMalloc((void **)&ret_pin, 4 * 3 * sizeof(float), 0)) return 1;
     double X[4 * 7], cost[4], hist_w[4 * 7], hist_c[4], secs[8];
-    int32_t nonf[1], flags[10], pending = 0;
+    int32_t nonf[1], flags[OCD_CMA_N_STOP], pending = 0;
     int64_t done = 0;
     ocd_cma_run_args a;
     memset(&a, 0, sizeof a);
     a.scn = scn; a.init_dev = init_dev; a.N = 3; a.S = 1; a.w_pinned = w_pin; a.ret_pinned = ret_pin; a.stream = NULL;
     a.rollout = (ocd_cma_rollout_fn)ocd_rollout_episodes; a.sync = ocd_stream_synchronize;
     a.normalise_variant = 1; a.max_generations = 1;
-    const double opts[10] = {1, INFINITY, 1e-11, 1e-12, 1e-11, 1e3, 1e14, 1e20, 1e9, 1};
+    const double opts[OCD_CMA_N_STOP] = {1, INFINITY, 1e-11, 1e-12, 1e-11, 1e3, 1e14, 1e20, 1e9, 1, 0, 0};
     memcpy(a.stop_opts, opts, sizeof opts);
     a.X = X; a.cost = cost; a.hist_w = hist_w; a.hist_cost = hist_c; a.seconds = secs; a.nonfinite = nonf;
     if (ocd_cma_run(es, &a, &done, flags, &pending) != 0) { fprintf(stderr, "ocd_cma_run failed: %s\n", ocd_last_error()); return 1; }

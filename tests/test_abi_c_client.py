@@ -63,6 +63,7 @@ def test_c_client_episodes_and_native_generation_match_the_oracle(client, oracle
     want = oracle.rollout(scn.desc, INITS, w32)["returns"]
     got = np.array([float(x) for x in line(r.stdout, "returns")], dtype=np.float32)
     assert np.array_equal(got, want.ravel())
+    assert "indexed rollout equals the flat call on 6 episodes" in r.stdout      # ocd_rollout_indexed, reverse order, in C
     # the generation: the rows the C loop normalised into pinned memory, the costs it told
     gen = line(r.stdout, "generation")
     assert gen[:6] == ["done", "1", "pending", "0", "maxiter", "1"] and gen[6] == "costs"
