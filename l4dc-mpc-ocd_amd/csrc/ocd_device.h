@@ -849,17 +849,30 @@ __device__ __forceinline__ float reward_one(const ocd_scenario_desc &d, const fl
 
     // reduce_min over the lanes: the gradient goes to the minimum, split equally among exact ties.  Ties are
     // rare: unless some live lane has one (wave-uniform test), the per-lane factors come precomputed.
+    // "some live lane has two lanes at the minimum" from the lane masks of the comparisons the selects below need anyway
+    // (scalar and / or: free beside the vector stream) instead of counting the ties per lane (two selects, an add, a
+    // compare: four vector slots per pass for an event that almost never happens)
     bool tie[L];
-    int ntie_min = 0;
+    unsigned long long tie_m[L], tie_two = 0ull, tie_seen = 0ull;
 #pragma unroll
-    for (int l = 0; l < L; ++l) { tie[l] = pl[l] == pmin; ntie_min += tie[l] ? 1 : 0; }
+    for (int l = 0; l < L; ++l) {
+        tie[l] = pl[l] == pmin;
+        tie_m[l] = __builtin_amdgcn_ballot_w64(tie[l]);
+        tie_two |= tie_seen & tie_m[l];
+        tie_seen |= tie_m[l];
+    }
     float qx = 0.0f;
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         const float g_r = (tie[l] ? lgc.g1[l] : lgc.g0[l]) * rl[l];
         qx = qx + g_r * -1.0f;
     }
-    if (__builtin_expect((__ballot(ntie_min > 1) & live_mask) != 0ull, 0)) {
+    if (__builtin_expect((tie_two & live_mask) != 0ull, 0)) {
+        float pm = pmin;
+        asm volatile("" : "+v"(pm));               // (the count stays HERE: not speculated into the pass by the optimiser)
+        int ntie_min = 0;
+#pragma unroll
+        for (int l = 0; l < L; ++l) ntie_min += (pl[l] == pm) ? 1 : 0;
         const float min_share = inv_count(ntie_min) * w_min;
         qx = 0.0f;
 #pragma unroll
