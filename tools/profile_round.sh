@@ -26,7 +26,7 @@ for c in $CONFIGS; do
         steps=30; [ "$n" -ge 4 ] && steps=6
         extra=""; tag=$n; [ "$c" != "$n" ] && { extra="--emulate-rank 0/8"; steps=20; tag="${n}_share8"; };;
     esac
-    args="bench.py --config $n $extra --steps $steps --warmup 2 --no-extras --no-cpu-baseline"
+    args="bench.py --config $n $extra --steps $steps --warmup 2 --no-extras --no-cpu-baseline --no-parity"
     cd /tmp
     rocprofv3 --kernel-trace --stats -d "$OUT/c${c}_stats" -o res -- python3 "$ROOT"/$args > "$OUT/c${c}_stats.log" 2>&1
     rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/c${c}_fetch" -o res -- python3 "$ROOT"/$args > "$OUT/c${c}_fetch.log" 2>&1

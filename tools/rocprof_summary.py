@@ -54,24 +54,31 @@ def counters_json(round_name, out_dir):
     for d in sorted(glob.glob(os.path.join(out_dir, "c*_sq"))):
         cfg = re.search(r"c(\d+s?|reference_\w+?)_sq$", d).group(1)   # "4" = the whole config, "4s" = one of 8 GPUs' share
         vals = {}
+        # THE planner kernel of this workload: the one the run spent most of its time in (a bench run may launch others --
+        # e.g. the small plan / trajectory launches of a parity sample -- which must not be mixed into its averages)
+        top = None
+        for path in glob.glob(os.path.join(out_dir, f"c{cfg}_stats", "**", "*.db"), recursive=True):
+            rows = list(sqlite3.connect(path).cursor().execute(
+                "select name from top_kernels where name like '%mpc_%kernel%' order by total_duration desc limit 1"))
+            top = rows[0][0] if rows else None
         for kind in ("fetch", "write", "sq", "stats"):
             for path in glob.glob(os.path.join(out_dir, f"c{cfg}_{kind}", "**", "*.db"), recursive=True):
                 cur = sqlite3.connect(path).cursor()
                 try:
                     for name, cnt, avg, grid, wg in cur.execute(
                             "select counter_name, count(*), avg(value), max(grid_size), max(workgroup_size) "
-                            "from counters_collection where kernel_name like '%mpc_%kernel%' group by counter_name"):
+                            "from counters_collection where kernel_name = ? group by counter_name", (top,)):
                         vals[name] = avg
                         vals["grid_size"], vals["workgroup_size"] = grid, wg
                 except sqlite3.Error:
                     pass
                 if kind == "stats":
                     try:
-                        for name, calls, avg in cur.execute("select name, total_calls, average from top_kernels where name like '%mpc_%kernel%'"):
+                        for name, calls, avg in cur.execute("select name, total_calls, average from top_kernels where name = ?", (top,)):
                             vals["kernel_avg_us"], vals["kernel_calls"], vals["kernel_name"] = avg, calls, name
                         # steady state: the later half of the dispatches (the first launches of a cold process run on
                         # clocks that are still rising -- bench.py's own kernel_ms is taken after its warm-up as well)
-                        durs = [r[0] for r in cur.execute("select duration from kernels where name like '%mpc_%kernel%' order by start")]
+                        durs = [r[0] for r in cur.execute("select duration from kernels where name = ? order by start", (top,))]
                         if durs:
                             tail = durs[len(durs) // 2:]
                             vals["kernel_steady_avg_us"] = sum(tail) / len(tail) / 1e3
