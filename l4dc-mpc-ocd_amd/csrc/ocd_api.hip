@@ -36,6 +36,7 @@ struct ocd_scenario {
     int32_t leaf_proj = 0;
     float *dev_leaf[OCD_MAX_DEVICES];
     int32_t n_cus[OCD_MAX_DEVICES];
+    int32_t two_sided = 0;                 // fence_shape * fence_width < 1/80: generic kernels, both fence sides (ocd_kernels.h)
     mutable int32_t last_launch[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ocd_scenario_last_launch (guarded by mu)
 };
 
@@ -91,12 +92,11 @@ int32_t validate(const ocd_scenario_desc *d)
     if (!(d->dt > 0.0f)) return fail(OCD_ERR_INVALID_ARG, "dt must be > 0");
     // smooth_threshold(x) = F1 / (F1 + F2), F = exp(-1 / (shape * .)): on the road side of the fence F1 = 0 and
     // F2 = exp(-1 / (shape * (width - xd))) with width - xd >= width.  The reference always has shape * width = c = 5
-    // (math_utils.py:88-95, merging.py:80).  Below 1/87 F2 flushes to 0 as well and the feature is 0/0 = NaN on the road
-    // itself; every evaluation of the kernels (ocd_device.h: reward_state and the forms derived from it) evaluates ONE side of
-    // the fence per lane and takes the other as exactly 0, which that NaN would break: refused rather than answered wrongly.
-    if (d->reward_kind == OCD_REWARD_LANE_FEATURES && !(d->fence_shape * d->fence_width >= 0.0125f))
-        return fail(OCD_ERR_UNSUPPORTED, "fence_shape * fence_width = %g < 1/80: smooth_threshold is 0/0 on the road (the reference's is 5)",
-                    (double)(d->fence_shape * d->fence_width));
+    // (math_utils.py:88-95, merging.py:80).  Below 1/87 F2 flushes to 0 as well and the feature is 0/0 = NaN on a band of the
+    // road in the reference itself; the specialised kernels (ocd_device.h: reward_state and the forms derived from it) evaluate
+    // ONE side of the fence per lane and take the other as exactly 0, which that NaN would break.  Round 4 refused such a
+    // descriptor; since round 5 it is accepted and its handle runs the generic kernels with both sides of the fence
+    // evaluated as merging.py:80-81 writes them (ocd_scenario::two_sided, set in ocd_scenario_create).
     if (d->reward_kind == OCD_REWARD_LANE_FEATURES && !(d->fence_lo >= 0.0f && d->fence_width > 0.0f))
         return fail(OCD_ERR_INVALID_ARG, "fence_lo must be >= 0 and fence_width > 0 (0.05*num_lanes - 0.05, 0.05)");
     return OCD_OK;
@@ -171,6 +171,13 @@ void base_params(const ocd_scenario *scn, ocd::KernelParams &p)
     p.no_latency_build = scn->opt_no_lat;
     p.reset_phase = scn->opt_reset_phase;
     p.chunk_size = scn->opt_chunk;
+    if (scn->two_sided) {                  // every feature of every lane, the generic LDS-window kernel (no specialised build)
+        p.two_sided = 1;
+        p.no_skips = 1;
+        p.force_full = ~0ull;
+        p.scan_mode = 1;
+        p.no_latency_build = 1;
+    }
 }
 
 int32_t launch(const ocd_scenario *scn, ocd::KernelParams &p, void *hip_stream)
@@ -318,6 +325,7 @@ int32_t ocd_scenario_create(const ocd_scenario_desc *desc, ocd_scenario **out)
     s->desc = *desc;
     s->K = desc->extra_inits ? 6 : 3;
     s->D = OCD_N_FEATURES(desc->reward_kind, desc->n_lanes);
+    s->two_sided = (desc->reward_kind == OCD_REWARD_LANE_FEATURES && !(desc->fence_shape * desc->fence_width >= 0.0125f)) ? 1 : 0;
     for (int i = 0; i < OCD_MAX_DEVICES; ++i) { s->dev_plans[i] = nullptr; s->dev_leaf[i] = nullptr; s->n_cus[i] = 0; }
     *out = s;
     return OCD_OK;

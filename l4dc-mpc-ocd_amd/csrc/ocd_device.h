@@ -210,7 +210,8 @@ __device__ __forceinline__ float reward_state(const ocd_scenario_desc &d, const 
                                               float x, float y, float v, float sn, float cn,
                                               const BumpGeom (&bg)[NO > 0 ? NO : 1], Q4 &q,
                                               float *feats /* nullptr or [D] global */,
-                                              const bool do_col = true, const bool do_fence = true)
+                                              const bool do_col = true, const bool do_fence = true,
+                                              const bool two_sided = false)
 {
     if (L == 0) {                                  // OCD_REWARD_TARGET_SPEED (the planner KAT car)
         const float dv = v - d.target_speed;
@@ -255,7 +256,7 @@ __device__ __forceinline__ float reward_state(const ocd_scenario_desc &d, const 
     float bxv[NOA], byv[NOA], col[NOA];
     float pcol = 0.0f;
     int ntie_col = NO;
-    ThrTape tp_f;
+    ThrTape tp_f, tp_m;
     const bool side_p = x > d.fence_lo;
     float Ssum = 0.0f, ax = 0.0f, pf = 0.0f;
     if (do_col) {
@@ -275,8 +276,18 @@ __device__ __forceinline__ float reward_state(const ocd_scenario_desc &d, const 
     // F1 = 0 exactly: S = 0/den = 0 and every adjoint term of that side is +-0 (see needs_fence).  So
     // one smooth_threshold evaluation on the possibly-active side gives S(x) + S(-x) and its gradient
     // bit for bit (x + 0 = x), at half the divisions and exponentials.
+    // two_sided (wave-uniform; the generic kernels only, for descriptors with fence_shape * fence_width < 1/80): the
+    // argument above needs F2 = exp(-1/(shape * (width - x_diff))) of the inactive side to be non-zero, i.e.
+    // shape * width >= 1/87.  Below that smooth_threshold is 0/0 = NaN on a band of the ROAD in the reference itself
+    // (merging.py:80-81 evaluates both sides), and both sides are evaluated here as the reference writes them.
     if (do_fence) {
-        Ssum = thr_fwd(side_p ? x : -x, d.fence_lo, d.fence_width, d.fence_shape, tp_f);
+        if (two_sided) {
+            const float Sp = thr_fwd(x, d.fence_lo, d.fence_width, d.fence_shape, tp_f);
+            const float Sm = thr_fwd(-x, d.fence_lo, d.fence_width, d.fence_shape, tp_m);
+            Ssum = Sp + Sm;
+        } else {
+            Ssum = thr_fwd(side_p ? x : -x, d.fence_lo, d.fence_width, d.fence_shape, tp_f);
+        }
         ax = (x < 0.0f) ? -x : x;
         pf = Ssum * ax;
     }
@@ -327,8 +338,13 @@ __device__ __forceinline__ float reward_state(const ocd_scenario_desc &d, const 
     if (do_fence) {
         const float g_Ssum = w_f * ax;
         const float g_ax = w_f * Ssum;
-        const float g_z = thr_bwd(g_Ssum, d.fence_shape, tp_f);
-        qx = qx + (side_p ? g_z : -g_z);
+        if (two_sided) {
+            qx = qx + thr_bwd(g_Ssum, d.fence_shape, tp_f);
+            qx = qx + (-thr_bwd(g_Ssum, d.fence_shape, tp_m));
+        } else {
+            const float g_z = thr_bwd(g_Ssum, d.fence_shape, tp_f);
+            qx = qx + (side_p ? g_z : -g_z);
+        }
         const float sgn = (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f);
         qx = qx + g_ax * sgn;
     }

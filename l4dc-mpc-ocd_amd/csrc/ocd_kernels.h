@@ -75,6 +75,9 @@ struct KernelParams {
     // instead of the flat (p, n, s) decomposition of ep_begin + prob; rows are clamped to [0, P_rows) / [0, N)
     const int32_t *ep_index;   // [n_problems, 3] or nullptr
     long long P_rows;          // rows of `weights` (indexed rollouts only)
+    // fence_shape * fence_width < 1/80: smooth_threshold is 0/0 on the road in the reference itself; such a handle runs the
+    // generic kernels only, every feature of every lane, BOTH sides of the fence as merging.py:80-81 writes them
+    int32_t two_sided;
 };
 
 // Which (candidate row, init row, entry of the teleport cycle) episode `prob` of a rollout launch runs (both planner

@@ -184,6 +184,8 @@ mpc_kernel(const KernelParams p)
 
     const float dt = d.dt, dt2 = d.dt_sq, fr = d.ego_friction, lr = d.learning_rate;
     constexpr int D = feat_dim(L);
+    // degenerate fence (KernelParams::two_sided): the generic kernel only -- a compile-time false in every specialised one
+    const bool two_sided = (HT == 0) && p.two_sided != 0;
 
     // ---- problem inputs -------------------------------------------------
     float ex, ey, ev, eth;                    // ego state
@@ -264,7 +266,7 @@ mpc_kernel(const KernelParams p)
             float s_, c_;
             sincos_(eth, s_, c_);
             Q4 qd;
-            const float r = reward_state<NO, L, false>(d, wd, ex, ey, ev, s_, c_, bgd, qd, nullptr);
+            const float r = reward_state<NO, L, false>(d, wd, ex, ey, ev, s_, c_, bgd, qd, nullptr, true, true, two_sided);
             G_ret = G_ret + r;
         }
 
@@ -551,7 +553,7 @@ mpc_kernel(const KernelParams p)
                     const unsigned long long full_m = multi_c | force_full_step | (any_feat & force_full_any);
                     if (__builtin_expect((any_feat | force_full_step) != 0ull, 1)) {
                         if (__builtin_expect(full_m != 0ull, 0)) {
-                            r = reward_state<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, true, true);
+                            r = reward_state<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, nullptr, true, true, two_sided);
                             OCD_STAMP(5); OCD_STAMP_COUNT(12);     // every feature
                         } else if (multi_f != 0ull) {
                             r = reward_fc<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, nc, q, pkc);
@@ -857,7 +859,7 @@ __global__ void reward_kernel(const KernelParams p, float *feats_out, float *rew
     sincos_(ws[3], s_, c_);
     Q4 q;
     const float r = reward_state<NO, L, false>(d, w, ws[0], ws[1], ws[2], s_, c_, bg, q,
-                                            feats_out ? feats_out + b * D : nullptr);
+                                            feats_out ? feats_out + b * D : nullptr, true, true, p.two_sided != 0);
     if (reward_out) reward_out[b] = r;
 }
 
@@ -937,7 +939,7 @@ __global__ void objective_kernel(const KernelParams p, const float *controls, fl
         sincos_(thn, sn, cn);
         float r;
         if (has_leaf && t == H - 1) r = leaf_value<true>(leaf, xn, yn, vn, sn, cn, tp.q);
-        else r = reward_state<NO, L, true>(d, w, xn, yn, vn, sn, cn, bg, tp.q, nullptr);
+        else r = reward_state<NO, L, true>(d, w, xn, yn, vn, sn, cn, bg, tp.q, nullptr, true, true, p.two_sided != 0);
         R = R + r;
         x = xn; y = yn; v = vn; th = thn; s_ = sn; c_ = cn;
         if (traj_out) {
@@ -1172,7 +1174,7 @@ hipError_t launch_mpc_dispatch(int H, int NO, int L, const KernelParams &p_in, h
 {
     const KernelParams &p = p_in;
     *supported = true;
-    OCD_KERNEL_TABLE(OCD_CASE)
+    if (!p.two_sided) { OCD_KERNEL_TABLE(OCD_CASE) }           // (a degenerate fence runs the generic kernel: ocd_kernels.h)
     OCD_PAIR_TABLE(OCD_GCASE)
     *supported = false;
     return hipSuccess;
