@@ -105,8 +105,10 @@ typedef struct ocd_scenario_desc {
     float lane_center[OCD_MAX_LANES]; /* StraightLane.p[0] per lane (world.py:150-151,157-158) */
     float fence_lo;             /* fp32(0.05*num_lanes - 0.05): threshold - width (math_utils.py:89, merging.py:80) */
     float fence_width;          /* 0.05 */
-    float fence_shape;          /* c / width = 100 (math_utils.py:85); fence_shape * fence_width (the reference's c = 5) must be
-                                 * >= 1/80, or smooth_threshold is 0/0 on the road itself: OCD_ERR_UNSUPPORTED */
+    float fence_shape;          /* c / width = 100 (math_utils.py:85).  fence_shape * fence_width is the reference's c = 5; below
+                                 * 1/80 smooth_threshold is 0/0 = NaN on a band of the road in the reference itself: such a
+                                 * descriptor is accepted and answered like the reference (NaN), by the generic kernels with
+                                 * both sides of the fence evaluated as merging.py:80-81 writes them (no specialised build) */
     float bump_half_x;          /* 0.08 (merging.py:72) */
     float bump_half_y;          /* 0.15 (merging.py:73) */
 

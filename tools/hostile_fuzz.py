@@ -59,8 +59,10 @@ def main():
         d.fence_lo = pick(rng, d.fence_lo, 1e-12, 1e4)
         d.fence_width = pick(rng, d.fence_width, 1e-9, 1e6, 0.4) or 0.05          # (validated > 0)
         d.fence_shape = pick(rng, float(np.float32(5.0) / np.float32(d.fence_width)), 1e-9, 1e12, 0.4)
-        if np.float32(d.fence_shape) * np.float32(d.fence_width) < 0.0125 and rng.random() < 0.85:
-            d.fence_shape = float(logu(rng, 0.0126, 50.0) / d.fence_width)       # (below 1/80 the library refuses the descriptor)
+        if np.float32(d.fence_shape) * np.float32(d.fence_width) < 0.0125 and rng.random() < 0.6:
+            # (below 1/80 smooth_threshold is 0/0 on the road in the reference itself: such handles run the generic
+            #  kernels with both fence sides -- round 4 refused them; 40 % of them stay in the mix)
+            d.fence_shape = float(logu(rng, 0.0126, 50.0) / d.fence_width)
         d.bump_half_x = pick(rng, d.bump_half_x, 1e-12, 1e8, 0.4)
         d.bump_half_y = pick(rng, d.bump_half_y, 1e-12, 1e8, 0.4)
         for i in range(L):
