@@ -539,9 +539,25 @@ def main():
         scn = scenarios.SCENARIOS[spec["scenario"]](horizon=spec["horizon"], **spec.get("kwargs", {}))
         runs = [(list(scn.init_dist.sample(spec["n_inits"], seed=300 + r)), 1 + r, 0.05) for r in range(R)]
         res = m.optimize_cmaes_many(runs, maxiter=gens, termination={"tolfacupx": float("inf"), "tolupsigma": float("inf")})
-        wall = np.array(res.generation_wall_seconds[-32:]) * 1e3
+        wall = np.array(res.generation_wall_seconds[-32:]) * 1e3       # (N > 1: the slowest rank's)
         nat = np.array(res.generation_seconds[-32:]) * 1e3
         E = int(res.episodes_per_generation[-1])
+        if world > 1:
+            # the runs were dealt over the ranks (run r on rank r mod N), each rank in lockstep on its own GPU, one
+            # all_gather_object at the end: the reference's Pool of processes as one process per GPU
+            E_all = sum(int(st["episodes_per_generation"][-1]) for st in res.per_rank if st)
+            return {"workload": f"{R} independent CMA-ES runs of {spec['label']} dealt over {world} ranks, each rank's runs in "
+                                f"lockstep: one launch per generation and rank",
+                    "runs": R, "ranks": world, "episodes_per_generation": E_all, "lockstep": bool(res.lockstep),
+                    "episodes_per_generation_per_rank": [int(st["episodes_per_generation"][-1]) if st else 0 for st in res.per_rank],
+                    "cma_generation_ms": float(np.median(wall)), "cma_generation_native_timers_ms": float(np.median(nat)),
+                    "cma_generation_ms_per_rank": [float(np.median(np.array(st["generation_wall_seconds"][-32:]) * 1e3)) if st else None
+                                                   for st in res.per_rank],
+                    "value": E_all / (float(np.median(wall)) * 1e-3), "unit": "episodes/s",
+                    "generations_run": len(res.generation_seconds), "launch": res.launch,
+                    "stop_reason": sorted({k for o in res.runs for k in o.stop_reason}),
+                    "collective": "none while the runs advance; one all_gather_object of the histories at the end",
+                    "sampler_parity": "unpinned (own CMA-ES, pycma absent); every run's history is bit for bit the run alone"}
         # the launch by itself: HIP events on the launch stream (torch's current stream is the one the launches go to)
         eng = m._engine()
         pop = res.runs[0].es.lam
@@ -777,6 +793,10 @@ def main():
                              sharding=f"population {P_c} split into {world} candidate blocks, one all_gather of fp32 "
                                       f"returns per generation inside the timed step, max-over-ranks wall-clock")
                     strong_blocks[f"config{c}"] = b
+        if world > 1 and not emulate:
+            lb = lockstep_block("reference_h5", REFERENCE_SHAPES["reference_h5"])   # every rank: its share of the 28 runs
+            if rank == 0:
+                reference_blocks["reference_h5_x28"] = lb
         cfg = spec_of(args.config)
         cma_pop = cfg["pop"] * world if args.scaling == "weak" else cfg["pop"]
         cma = cma_generations(cfg, cma_pop, reduce_over_ranks=True)

@@ -115,8 +115,20 @@ def main(argv=None):
         raise SystemExit("'vis' renders GIFs / heat maps with pyglet + moviepy: outside the accelerated planner path")
     if args.n_inits == 1:
         args.one_by_one = False
+    # under a launcher (python -m torch.distributed.run --nproc-per-node G ... run_mpc_ord ... --one_by_one): one rank per GPU;
+    # the optimisations are dealt over the ranks (optimize_cmaes_lockstep), a single optimisation shards its population
+    import os
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_size > 1:
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
+            dist.init_process_group(os.environ.get("OCD_DIST_BACKEND", "nccl"))
+        if args.seed is None:
+            raise SystemExit("--seed is required under a launcher: every rank must draw the same init states and seeds")
     env = envs[args.scenario]
-    optimization_seed = np.random.randint(0, 2 ** 31)
+    optimization_seed = np.random.randint(0, 2 ** 31) if world_size == 1 else (args.seed * 7919 + 1) % (2 ** 31)
     if args.seed is None:
         args.seed = optimization_seed
     env_seeds = [(args.seed * 1000000 + i) % (2 ** 32) for i in range(args.n_inits)]

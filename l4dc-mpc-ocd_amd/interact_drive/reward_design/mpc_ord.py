@@ -225,7 +225,8 @@ class MPC_ORD:
         init = self._init_key_array(inits)
         P, N, S, D = W.shape[0], init.shape[0], self.num_samples, W.shape[1]
         init_dev = self._init_states_dev(eng, init)
-        sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        sharded = (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+                   and not getattr(self, "_local_only", False))      # (lockstep over RUNS shards the runs, not a population)
         e0, e1 = sharding.episode_range(P, N, S, dist.get_world_size(), dist.get_rank()) if sharded else (0, P * N * S)
         st = self._staging(eng, P, N, S, D, e1 - e0)
         # three float64 normalisations + the fp32 cast, written straight into the pinned rows the kernel reads
@@ -387,7 +388,7 @@ class MPC_ORD:
         from ...scenarios import _native_normalise_variant
         if self.save_path is not None or getattr(self, "force_python_loop", False):
             return False
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and not getattr(self, "_local_only", False):
             return False
         return hasattr(es, "run") and _native_normalise_variant(self.weight_dim) is not None
 
@@ -522,18 +523,29 @@ class LockstepResult:
     `lockstep` (True: one launch per generation for all runs; False: the runs were made one after another),
     `generation_seconds` / `generation_wall_seconds` (per lockstep generation: native timers / including the
     interpreter's bookkeeping), `episodes_per_generation` (episodes of each generation's launch), `host_split`
-    (seconds per segment and generation, as MPC_ORD.host_split), `launch` (what the last launch chose)."""
+    (seconds per segment and generation, as MPC_ORD.host_split), `launch` (what the last launch chose); under
+    torch.distributed `ranks` and `per_rank` (the timing fields above are then the slowest rank's)."""
 
     def __init__(self, runs):
         self.runs, self.best, self.lockstep = runs, [], True
         self.generation_seconds, self.generation_wall_seconds, self.episodes_per_generation = [], [], []
         self.host_split, self.launch = {}, None
+        self.ranks, self.per_rank = 1, None      # torch.distributed: ranks the runs were dealt over, each rank's timings
 
     def host_split_ms(self):
         return {k: float(np.median(v[-32:]) * 1e3) for k, v in self.host_split.items()}
 
 
 def optimize_cmaes_lockstep(ords, seeds, sigma0s, popsize=None, maxiter=None, maxfevals=None, termination=None, chunk=32):
+    """See _lockstep_local (one process) and _lockstep_over_ranks (torch.distributed): the public entry point."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and \
+            not any(getattr(o, "_local_only", False) for o in ords):
+        return _lockstep_over_ranks(ords, seeds, sigma0s, popsize, maxiter, maxfevals, termination, chunk)
+    return _lockstep_local(ords, seeds, sigma0s, popsize, maxiter, maxfevals, termination, chunk)
+
+
+def _lockstep_local(ords, seeds, sigma0s, popsize=None, maxiter=None, maxfevals=None, termination=None, chunk=32):
     """MPC_ORD.optimize_cmaes (mpc_ord.py:33-45) for R MPC_ORD objects over the SAME world, car and planner -- their init
     states, seeds and step sizes differ -- with the generation's episodes of ALL runs in one launch.
 
@@ -545,12 +557,15 @@ def optimize_cmaes_lockstep(ords, seeds, sigma0s, popsize=None, maxiter=None, ma
     stream; NaN costs redrawn by the same Python code), so histories, pickles, stop reasons and counters are bit for
     bit those of the runs made one after another; a run that stops drops out of the launch.
 
-    Falls back to making the runs one after another (same results) when lockstep is not possible: under
-    torch.distributed with more than one rank, with force_python_loop, or where the native weight normalisation does
-    not reproduce numpy's on this machine."""
+    Under torch.distributed with G ranks the RUNS are dealt over the ranks (run r on rank r mod G: the reference's
+    Pool of processes as one process per GPU) -- each rank advances its runs in lockstep on its own GPU, nothing is
+    exchanged while they run, and ONE all_gather_object at the end hands every rank the histories, stop reasons and
+    best candidates of all runs (`res.runs[k].es` is None for a run another rank made).
+
+    Falls back to making the runs one after another (same results) when lockstep is not possible: with
+    force_python_loop, or where the native weight normalisation does not reproduce numpy's on this machine."""
     import ctypes as C
     import torch
-    import torch.distributed as dist
     from .cmaes import MAX_RUNS, RunManyArgs, STOP_NAMES, N_STOP, load_cma_library
     from ...scenarios import _native_normalise_variant
     R = len(ords)
@@ -561,11 +576,10 @@ def optimize_cmaes_lockstep(ords, seeds, sigma0s, popsize=None, maxiter=None, ma
     D = first.weight_dim
     engines = [o._engine() for o in ords]
     overrides = dict(maxiter=maxiter, maxfevals=maxfevals, **(termination or {}))
-    sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     odd = any(hasattr(o.world, "unlucky_car_idx") and (len(o.init_car_states) * o.num_samples) % 2 for o in ords)
     if (any(e is not engines[0] for e in engines) or any(o.weight_dim != D or o.num_samples != first.num_samples for o in ords)):
         raise ValueError("optimize_cmaes_lockstep: the runs must share world, car, planner arguments and num_samples")
-    if (sharded or R > MAX_RUNS or odd or _native_normalise_variant(D) is None
+    if (R > MAX_RUNS or odd or _native_normalise_variant(D) is None
             or any(getattr(o, "force_python_loop", False) for o in ords)):
         res.lockstep = False
         for o, seed, sigma0 in zip(ords, seeds, sigma0s):
@@ -696,3 +710,59 @@ def finite_horizon_env(horizon=5, env_seeds=[1], debug=True, extra_inits=False):
     our_car, _, world = world_from_scenario(scn, init_states[0], debug=debug,
                                             visualizer_args=dict(name="Switch Lanes"))
     return our_car, world, init_states
+
+
+def _lockstep_over_ranks(ords, seeds, sigma0s, popsize, maxiter, maxfevals, termination, chunk):
+    """optimize_cmaes_lockstep under torch.distributed: rank g makes runs g, g + G, g + 2G, ... in lockstep on its own GPU
+    (no collective while they run -- the runs are independent, run_mpc_ord.py:83-90), then one all_gather_object."""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    mine = list(range(rank, len(ords), world))
+    for o in ords:
+        o._local_only = True
+    try:
+        local = None
+        if mine:
+            # (the distributed flag is read through dist.get_world_size(): the local call sees itself as unsharded
+            #  because every MPC_ORD it touches is marked _local_only)
+            local = _lockstep_local([ords[k] for k in mine], [seeds[k] for k in mine], [sigma0s[k] for k in mine],
+                                    popsize, maxiter, maxfevals, termination, chunk)
+        payload = {}
+        for j, k in enumerate(mine):
+            o = ords[k]
+            payload[k] = dict(history=[(np.asarray(w), float(r)) for w, r in o.history], seed=o.history.seed, iter=o.iter,
+                              stop_reason=o.stop_reason, n_nonfinite=list(o.n_nonfinite), n_resampled=o.n_resampled,
+                              generation_seconds=list(o.generation_seconds), best=np.asarray(local.best[j]),
+                              best_f=float(o.es.best_f))
+        stats = None if local is None else dict(generation_seconds=local.generation_seconds,
+                                                generation_wall_seconds=local.generation_wall_seconds,
+                                                episodes_per_generation=local.episodes_per_generation,
+                                                lockstep=local.lockstep, launch=local.launch)
+        everything = [None] * world
+        dist.all_gather_object(everything, (payload, stats))
+    finally:
+        for o in ords:
+            o._local_only = False
+    res = LockstepResult(list(ords))
+    res.ranks = world
+    res.per_rank = [st for _, st in everything]
+    res.lockstep = all(st is None or st["lockstep"] for _, st in everything)
+    slowest = max((st for _, st in everything if st is not None), key=lambda st: sum(st["generation_wall_seconds"]), default=None)
+    if slowest is not None:                                            # the job lasts as long as its slowest rank
+        res.generation_seconds, res.generation_wall_seconds = slowest["generation_seconds"], slowest["generation_wall_seconds"]
+        res.episodes_per_generation, res.launch = slowest["episodes_per_generation"], slowest["launch"]
+    best = {}
+    for pl, _ in everything:
+        for k, rec in pl.items():
+            o = ords[k]
+            if k not in mine:                                          # a run another rank made: its results, no strategy object
+                o.history = list2(rec["history"])
+                o.history.seed = rec["seed"]
+                o.iter, o.stop_reason = rec["iter"], rec["stop_reason"]
+                o.n_nonfinite, o.n_resampled = rec["n_nonfinite"], rec["n_resampled"]
+                o.generation_seconds = rec["generation_seconds"]
+                o.es, o.done, o.should_save_history = None, True, False
+                o.best_f = rec["best_f"]
+            best[k] = rec["best"]
+    res.best = [best[k] for k in range(len(ords))]
+    return res

@@ -125,3 +125,40 @@ def test_cli_one_by_one_runs_in_lockstep(hip, capsys):
                             "--opt_seeds", "11", "12", "--sequential"])
     for (a, _), (b, _) in zip(res, seq):
         assert all(np.array_equal(x[0], y[0]) and same(x[1], y[1]) for x, y in zip(a.history, b.history))
+
+
+def test_lockstep_deals_the_runs_over_ranks(hip, tmp_path):
+    """Under torch.distributed the RUNS are dealt over the ranks (the reference's Pool of processes, run_mpc_ord.py:83-90,
+    as one process per GPU): each rank advances its runs in lockstep, one all_gather_object at the end.  Two gloo ranks on
+    the one card: both hold all seven histories afterwards, bit for bit those of the one-process lockstep run."""
+    import os
+    import subprocess
+    import sys
+    from l4dc_mpc_ocd_amd.interact_drive.experiments.run_mpc_ord import make_mpc_ord
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import lockstep_ranks_helper as helper
+    out = str(tmp_path / "ranks")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(30900 + os.getpid() % 200), helper.__file__, out, "replanning"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    scn = scenarios.replanning(horizon=5)
+    base = make_mpc_ord("replanning", horizon=5, n_inits=1, seed=1)
+    one = base.optimize_cmaes_many(helper.runs_of(scn), maxiter=4)
+    assert one.lockstep and one.ranks == 1
+    got = []
+    for rank in range(2):
+        with open(f"{out}.rank{rank}", "rb") as f:
+            got.append(pickle.load(f))
+    for g in got:
+        assert g["ranks"] == 2 and g["lockstep"] and g["made_here"] == [k % 2 == g["rank"] for k in range(7)]
+        for k in range(7):
+            ref = one.runs[k]
+            assert len(g["histories"][k]) == len(ref.history) == 1 + 4 * 9
+            assert all(np.array_equal(a[0], b[0]) and same(a[1], b[1]) for a, b in zip(g["histories"][k], ref.history)), k
+            assert g["seeds"][k] == ref.history.seed and g["stops"][k] == ref.stop_reason and g["iters"][k] == ref.iter
+            assert np.array_equal(g["best"][k], one.best[k])
+    # rank 0 made runs 0, 2, 4, 6 and rank 1 runs 1, 3, 5: their launches hold those runs' episodes only
+    E = [9 * len(r[0]) * scn.desc.n_samples for r in helper.runs_of(scn)]
+    assert got[0]["episodes"][0][0] == sum(E[0::2]) and got[0]["episodes"][1][0] == sum(E[1::2])

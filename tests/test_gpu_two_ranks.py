@@ -92,6 +92,12 @@ def test_two_ranks_carry_baseline_configs_4_and_5_with_parity():
         assert par["episodes_checked"] >= 128 and par["bitwise_equal"] == par["episodes_checked"] == par["within_1e-4_rel"]
         assert par["argmin_flips"] == 0 and par["plan_steps_checked"] > 0
     assert two["parity"]["ranks"] == c4["parity"]["ranks"] == 2 and two["config2"]["parity"]["ranks"] == 1
+    # the reference's Pool over independent runs as one process per GPU: 28 runs dealt over the two ranks, each rank's 14 in
+    # lockstep (one launch of 14 x 27 episodes per generation and rank), nothing exchanged until the end
+    x28 = two["reference_h5_x28"]
+    assert x28["runs"] == 28 and x28["ranks"] == 2 and x28["lockstep"] is True
+    assert x28["episodes_per_generation_per_rank"] == [378, 378] and x28["episodes_per_generation"] == 756
+    assert len(x28["cma_generation_ms_per_rank"]) == 2 and x28["cma_generation_ms"] >= max(x28["cma_generation_ms_per_rank"]) - 1e-9
     assert two["parity"]["episodes_checked"] >= 256 and c5["parity"]["episodes_checked"] >= 256
     # the same populations whole on one rank: identical generation costs
     for c, blk in ((4, c4), (5, c5)):
