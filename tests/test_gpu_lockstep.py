@@ -162,3 +162,20 @@ def test_lockstep_deals_the_runs_over_ranks(hip, tmp_path):
     # rank 0 made runs 0, 2, 4, 6 and rank 1 runs 1, 3, 5: their launches hold those runs' episodes only
     E = [9 * len(r[0]) * scn.desc.n_samples for r in helper.runs_of(scn)]
     assert got[0]["episodes"][0][0] == sum(E[0::2]) and got[0]["episodes"][1][0] == sum(E[1::2])
+
+
+def test_cli_under_a_launcher_deals_the_runs_over_ranks(hip):
+    """run_mpc_ord.py started by torch.distributed.run (two gloo ranks on the one card): the three --one_by_one
+    optimisations are dealt over the ranks; every rank prints all three results."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(OCD_DIST_BACKEND="gloo", PYTHONPATH=root + os.pathsep + env.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(31200 + os.getpid() % 200), "-m", "l4dc_mpc_ocd_amd.interact_drive.experiments.run_mpc_ord",
+                        "finite_horizon", "cmaes", "--n_inits", "3", "--seed", "3", "--maxiter", "2", "--one_by_one"],
+                       capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert r.stdout.count("evaluations 19 ") == 6                  # 3 runs x (1 + 2 x 9) evaluations, printed by both ranks
