@@ -390,16 +390,16 @@ mpc_chunk_kernel(const KernelParams p)
                     if (__builtin_expect((multi_f | multi_c | beyond) != 0ull, 0)) {
                         if (__builtin_expect(beyond != 0ull, 0)) {
                             if ((multi_c | widths_degenerate) != 0ull)
-                                rw[s] = reward_every<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], q[s], pkc);
+                                rw[s] = reward_every<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], q[s], pkc, &lgc, lm);
                             else if (multi_f != 0ull)
-                                rw[s] = reward_fc<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], nc, q[s], pkc);
+                                rw[s] = reward_fc<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], nc, q[s], pkc, &lgc, lm);
                             else
                                 rw[s] = reward_one<NO, L, GRAD, false>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], br[s], nc, nf, true,
                                                                        true, q[s], pkc, lgc, lm);
                         } else if (multi_c != 0ull)
-                            rw[s] = reward_every<NO, L, GRAD, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], q[s], pkc);
+                            rw[s] = reward_every<NO, L, GRAD, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], q[s], pkc, &lgc, lm);
                         else
-                            rw[s] = reward_fc<NO, L, GRAD, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], nc, q[s], pkc);
+                            rw[s] = reward_fc<NO, L, GRAD, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], nc, q[s], pkc, &lgc, lm);
                         OCD_STAMP(5); OCD_STAMP_COUNT(12);
                     } else {
                         rw[s] = reward_one<NO, L, GRAD, false, false, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], br[s], nc, nf, true,

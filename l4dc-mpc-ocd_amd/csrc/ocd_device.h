@@ -352,6 +352,56 @@ __device__ __forceinline__ float reward_state(const ocd_scenario_desc &d, const 
     return r;
 }
 
+// Lane-feature gradient factors of one trajectory, precomputed once per kernel (lane_grad_const below): per lane l the
+// chain  g = w_l (+ w_min when lane l is the sole minimum) ; g * 10 ; * 2  of the backward pass, and x_hi, the guard of the
+// shortened reciprocals.
+template <int L>
+struct LaneGradConst { float g0[L > 0 ? L : 1], g1[L > 0 ? L : 1]; float x_hi; };
+
+// dr/dx through the lane features (merging.py:55-66: distances to the lane medians and their reduce_min) for the
+// multi-feature evaluations, in the form reward_one uses: the per-lane factors come precomputed (LaneGradConst), ties of the
+// minimum are detected on the lane masks of the comparisons (scalar and / or, free beside the vector stream), and only a
+// pass in which some live lane HAS a tie recomputes the chain with the tie count -- bit for bit the plain chain
+//   gl = w_l (+ (1 / ntie) w_min on the minimum) ; (gl * 10) * 2 * r_l ; qx += . * -1.
+template <int L>
+__device__ __forceinline__ float lane_grad_qx(const float (&w)[OCD_MAX_FEATURES], const float (&pl)[L], const float (&rl)[L],
+                                              float pmin, const LaneGradConst<L> &lgc, unsigned long long live_mask)
+{
+    bool tie[L];
+    unsigned long long tie_two = 0ull, tie_seen = 0ull;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        tie[l] = pl[l] == pmin;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(tie[l]);
+        tie_two |= tie_seen & m;
+        tie_seen |= m;
+    }
+    float qx = 0.0f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const float g_r = (tie[l] ? lgc.g1[l] : lgc.g0[l]) * rl[l];
+        qx = qx + g_r * -1.0f;
+    }
+    if (__builtin_expect((tie_two & live_mask) != 0ull, 0)) {
+        float pm = pmin;
+        asm volatile("" : "+v"(pm));               // (the count stays in this branch)
+        int ntie_min = 0;
+#pragma unroll
+        for (int l = 0; l < L; ++l) ntie_min += (pl[l] == pm) ? 1 : 0;
+        const float min_share = inv_count(ntie_min) * w[L + 1];
+        qx = 0.0f;
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            float gl = w[1 + l];
+            gl = tie[l] ? (gl + min_share) : gl;
+            const float g_d2 = gl * 10.0f;
+            const float g_r = (g_d2 * 2.0f) * rl[l];
+            qx = qx + g_r * -1.0f;
+        }
+    }
+    return qx;
+}
+
 // ---------------------------------------------------------------- reward, fence + at most ONE scripted car per lane
 // Precondition (WAVE-UNIFORM, proved by the caller with needs_collision1): no live lane is inside the collision box
 // of MORE THAN ONE scripted car; nc[j] marks the lanes inside car j's box.  The fence is evaluated for every lane
@@ -367,8 +417,10 @@ template <int NO, int L, bool GRAD, bool FASTDIV = false>
 __device__ __forceinline__ float reward_fc(const ocd_scenario_desc &d, const float (&w)[OCD_MAX_FEATURES],
                                            float x, float y, float v, float sn, float cn,
                                            const BumpGeom (&bg)[NO > 0 ? NO : 1], const bool (&nc)[NO > 0 ? NO : 1], Q4 &q,
-                                           const PkConsts &pkc)
+                                           const PkConsts &pkc, const LaneGradConst<L> *lgc = nullptr,
+                                           const unsigned long long live_mask = ~0ull)
 {
+    // lgc (straight-line builds): the lane-feature gradient through the precomputed per-lane factors (lane_grad_qx)
     static_assert(L > 0 && NO > 0, "lane-feature reward only");
     const float tgt = d.target_speed;
     const float bound = 4.0f * (tgt * tgt);
@@ -459,14 +511,18 @@ __device__ __forceinline__ float reward_fc(const ocd_scenario_desc &d, const flo
     q.qth = g_sn * cn;
 
     float qx = 0.0f, qy = 0.0f;
-    const float min_share = inv_count(ntie_min) * w_min;
+    if (lgc != nullptr) {
+        qx = lane_grad_qx<L>(w, pl, rl, pmin, *lgc, live_mask);
+    } else {
+        const float min_share = inv_count(ntie_min) * w_min;
 #pragma unroll
-    for (int l = 0; l < L; ++l) {
-        float gl = w[1 + l];
-        gl = (pl[l] == pmin) ? (gl + min_share) : gl;
-        const float g_d2 = gl * 10.0f;
-        const float g_r = (g_d2 * 2.0f) * rl[l];
-        qx = qx + g_r * -1.0f;
+        for (int l = 0; l < L; ++l) {
+            float gl = w[1 + l];
+            gl = (pl[l] == pmin) ? (gl + min_share) : gl;
+            const float g_d2 = gl * 10.0f;
+            const float g_r = (g_d2 * 2.0f) * rl[l];
+            qx = qx + g_r * -1.0f;
+        }
     }
     // the evaluated car is among the maxima in both cases: alone (product > 0) or tied with all NO cars (product 0)
     const float col_share = ((NO == 1) ? 1.0f : ((pcol == 0.0f) ? inv_count(NO) : 1.0f)) * w_col;
@@ -529,7 +585,8 @@ __device__ __forceinline__ float reward_fc(const ocd_scenario_desc &d, const flo
 template <int L, bool GRAD, bool FASTDIV = false>
 __device__ __forceinline__ float reward_fcc(const ocd_scenario_desc &d, const float (&w)[OCD_MAX_FEATURES],
                                             float x, float y, float v, float sn, float cn,
-                                            const BumpGeom (&bg)[2], Q4 &q, const PkConsts &pkc)
+                                            const BumpGeom (&bg)[2], Q4 &q, const PkConsts &pkc,
+                                            const LaneGradConst<L> *lgc = nullptr, const unsigned long long live_mask = ~0ull)
 {
     static_assert(L > 0, "lane-feature reward only");
     const float tgt = d.target_speed;
@@ -610,14 +667,18 @@ __device__ __forceinline__ float reward_fcc(const ocd_scenario_desc &d, const fl
     q.qth = g_sn * cn;
 
     float qx = 0.0f, qy = 0.0f;
-    const float min_share = inv_count(ntie_min) * w_min;
+    if (lgc != nullptr) {
+        qx = lane_grad_qx<L>(w, pl, rl, pmin, *lgc, live_mask);
+    } else {
+        const float min_share = inv_count(ntie_min) * w_min;
 #pragma unroll
-    for (int l = 0; l < L; ++l) {
-        float gl = w[1 + l];
-        gl = (pl[l] == pmin) ? (gl + min_share) : gl;
-        const float g_d2 = gl * 10.0f;
-        const float g_r = (g_d2 * 2.0f) * rl[l];
-        qx = qx + g_r * -1.0f;
+        for (int l = 0; l < L; ++l) {
+            float gl = w[1 + l];
+            gl = (pl[l] == pmin) ? (gl + min_share) : gl;
+            const float g_d2 = gl * 10.0f;
+            const float g_r = (g_d2 * 2.0f) * rl[l];
+            qx = qx + g_r * -1.0f;
+        }
     }
     const float col_share = inv_count(ntie_col) * w_col;
     const v2f SH = {(col0 == pcol) ? col_share : 0.0f, (col1 == pcol) ? col_share : 0.0f};
@@ -666,10 +727,12 @@ __device__ __forceinline__ float reward_fcc(const ocd_scenario_desc &d, const fl
 template <int NO, int L, bool GRAD, bool FASTDIV = false>
 __device__ __forceinline__ float reward_every(const ocd_scenario_desc &d, const float (&w)[OCD_MAX_FEATURES],
                                               float x, float y, float v, float sn, float cn,
-                                              const BumpGeom (&bg)[NO > 0 ? NO : 1], Q4 &q, const PkConsts &pkc)
+                                              const BumpGeom (&bg)[NO > 0 ? NO : 1], Q4 &q, const PkConsts &pkc,
+                                              const LaneGradConst<(L > 0 ? L : 1)> *lgc = nullptr,
+                                              const unsigned long long live_mask = ~0ull)
 {
 #ifndef OCD_NO_PACKED
-    if constexpr (NO == 2 && L > 0) return reward_fcc<L, GRAD, FASTDIV>(d, w, x, y, v, sn, cn, bg, q, pkc);
+    if constexpr (NO == 2 && L > 0) return reward_fcc<L, GRAD, FASTDIV>(d, w, x, y, v, sn, cn, bg, q, pkc, lgc, live_mask);
     else
 #endif
     return reward_state<NO, L, GRAD>(d, w, x, y, v, sn, cn, bg, q, nullptr, true, true);
@@ -688,8 +751,6 @@ __device__ __forceinline__ float reward_every(const ocd_scenario_desc &d, const 
 // xc^2 < 1 in fp32, i.e. in [2^-24, 1]; where an evaluation runs the fence units on a lane outside the fence region
 // (reward_fc, reward_fcc) theirs are shape * 0.01 and shape * (width + [0, 2 fence_lo]) <= 3 * 2^39 (a <= 2^39 too) --
 // all far inside what recip_pair_guarded needs.
-template <int L>
-struct LaneGradConst { float g0[L > 0 ? L : 1], g1[L > 0 ? L : 1]; float x_hi; };
 
 template <int L>
 __device__ __forceinline__ LaneGradConst<L> lane_grad_const(const float (&w)[OCD_MAX_FEATURES], const ocd_scenario_desc &d)

@@ -526,11 +526,11 @@ mpc_kernel(const KernelParams p)
                     // passes of the slowest wavefronts): decided before the evaluation, one evaluation per pass
                     if (__builtin_expect((multi_f | multi_c | beyond) != 0ull, 0)) {
                         if (__builtin_expect(beyond != 0ull, 0)) {
-                            if ((multi_c | widths_degenerate) != 0ull) r = reward_every<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, pkc);
-                            else if (multi_f != 0ull) r = reward_fc<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, nc, q, pkc);
+                            if ((multi_c | widths_degenerate) != 0ull) r = reward_every<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, pkc, &lgc, feat_mask);
+                            else if (multi_f != 0ull) r = reward_fc<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, nc, q, pkc, &lgc, feat_mask);
                             else r = reward_one<NO, L, GRAD, false, phi0_in_chain>(d, w, xn, yn, vn, sn, cn, bg, br, nc, nf, true, true, q, pkc, lgc, feat_mask);
-                        } else if (multi_c != 0ull) r = reward_every<NO, L, GRAD, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, pkc);
-                        else r = reward_fc<NO, L, GRAD, GRAD>(d, w, xn, yn, vn, sn, cn, bg, nc, q, pkc);
+                        } else if (multi_c != 0ull) r = reward_every<NO, L, GRAD, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, pkc, &lgc, feat_mask);
+                        else r = reward_fc<NO, L, GRAD, GRAD>(d, w, xn, yn, vn, sn, cn, bg, nc, q, pkc, &lgc, feat_mask);
                         OCD_STAMP(5); OCD_STAMP_COUNT(12); // every feature / fence + one car per lane / full divisions
                     } else {
                         r = reward_one<NO, L, GRAD, false, phi0_in_chain, GRAD>(d, w, xn, yn, vn, sn, cn, bg, br, nc, nf, true, true, q, pkc, lgc, feat_mask);
@@ -543,8 +543,8 @@ mpc_kernel(const KernelParams p)
                     r = reward_one<NO, L, GRAD, false, phi0_in_chain, GRAD>(d, w, xn, yn, vn, sn, cn, bg, br, nc, nf, true, true, q, pkc, lgc, feat_mask);
                     OCD_STAMP(6); OCD_STAMP_COUNT(13);     // one feature per lane
                     if (__builtin_expect((multi_f | multi_c | beyond) != 0ull, 0)) {
-                        if ((multi_c | widths_degenerate) != 0ull) r = reward_every<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, pkc);
-                        else if (multi_f != 0ull) r = reward_fc<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, nc, q, pkc);
+                        if ((multi_c | widths_degenerate) != 0ull) r = reward_every<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, q, pkc, &lgc, feat_mask);
+                        else if (multi_f != 0ull) r = reward_fc<NO, L, GRAD>(d, w, xn, yn, vn, sn, cn, bg, nc, q, pkc, &lgc, feat_mask);
                         else r = reward_one<NO, L, GRAD, false, phi0_in_chain>(d, w, xn, yn, vn, sn, cn, bg, br, nc, nf, true, true, q, pkc, lgc, feat_mask);
                         OCD_STAMP(5); OCD_STAMP_COUNT(12); // every feature / fence + one car per lane / full divisions
                     }
