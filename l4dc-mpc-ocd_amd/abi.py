@@ -113,6 +113,7 @@ HIP_SYMBOLS = [
     ("ocd_debug_math", C.c_int32, [_VP, _VP, _VP, _VP, C.c_int64, _VP]),
     ("ocd_debug_packed_math", C.c_int32, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, _VP]),
     ("ocd_debug_guarded_division", C.c_int32, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, _VP]),
+    ("ocd_debug_feature_variants", C.c_int32, [_VP, _VP, _VP, _VP, _VP, C.c_int64, _VP]),
     ("ocd_time_rollout", C.c_int32,
      [_VP, _VP, _VP, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _VP, C.c_int32,
       C.POINTER(C.c_float), _VP]),

@@ -641,6 +641,29 @@ int32_t ocd_debug_guarded_division(const float *u, const float *n, const float *
     return OCD_OK;
 }
 
+int32_t ocd_debug_feature_variants(const ocd_scenario *scn, const float *world_state, const float *weights, float *out,
+                                   int32_t *valid, int64_t B, void *hip_stream)
+{
+    if (!scn) return fail(OCD_ERR_INVALID_ARG, "scenario is NULL");
+    if (B < 0) return fail(OCD_ERR_INVALID_ARG, "B = %lld < 0", (long long)B);
+    if (B == 0) return OCD_OK;
+    if (!world_state || !weights || !out || !valid) return fail(OCD_ERR_INVALID_ARG, "world_state / weights / out / valid is NULL");
+    if (scn->desc.reward_kind != OCD_REWARD_LANE_FEATURES) return fail(OCD_ERR_UNSUPPORTED, "lane-feature rewards only");
+    int32_t st = need_device();
+    if (st != OCD_OK) return st;
+    ocd::KernelParams p;
+    base_params(scn, p);
+    p.ego_states = world_state;
+    p.weights = weights;
+    p.n_problems = B;
+    bool supported = false;
+    hipError_t e = ocd::launch_feature_variants(scn->desc.n_cars - 1, scn->desc.n_lanes, p, out, valid, (hipStream_t)hip_stream, &supported);
+    if (!supported) return fail(OCD_ERR_UNSUPPORTED, "feature variants: %d scripted cars, %d lanes (compiled: (1,2) (1,3) (2,2) (2,3) (3,3))",
+                                scn->desc.n_cars - 1, scn->desc.n_lanes);
+    if (e != hipSuccess) return hip_fail(e, "feature_variants_kernel launch");
+    return OCD_OK;
+}
+
 int32_t ocd_time_rollout(const ocd_scenario *scn, const float *init_states, const float *cand_weights,
                          int64_t P, int64_t N, int64_t ep_begin, int64_t ep_end,
                          float *returns_out, int32_t reps, float *ms_out, void *hip_stream)

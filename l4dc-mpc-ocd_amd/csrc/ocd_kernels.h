@@ -164,6 +164,8 @@ hipError_t launch_reward(int NO, int L, const KernelParams &p, float *feats, flo
 // R(u) and dR/du for caller-supplied controls [B,H,2] (naive_planner.py:33-77)
 hipError_t launch_objective(int NO, int L, const KernelParams &p, const float *controls, float *reward_out,
                             float *grad_out, float *traj_out, hipStream_t st, bool *supported);
+// the reward evaluations of ocd_device.h side by side (ocd_debug_kernels.hip): out [B, 8, 5], valid [B, 8]
+hipError_t launch_feature_variants(int NO, int L, const KernelParams &p, float *out, int32_t *valid, hipStream_t st, bool *supported);
 hipError_t launch_math(const float *in, float *e, float *s, float *c, long long n, hipStream_t st);
 hipError_t launch_packed_math(const float *num, const float *den, const float *x, float *div_scalar, float *div_packed,
                               float *exp_scalar, float *exp_packed, long long n_pairs, hipStream_t st);

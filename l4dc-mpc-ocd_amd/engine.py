@@ -395,6 +395,19 @@ class Engine(DeviceOps):
             out["traj"] = self._host(traj)
         return out
 
+    def feature_variants(self, world_state, weights):
+        """(out [B, 8, 5], valid [B, 8]): every hand-written form of the reward evaluation on the same world states
+        (include/ocd.h: ocd_debug_feature_variants) -- test support."""
+        d = self.desc
+        ws = self._to_dev(world_state).reshape(-1, d.n_cars, 4)
+        B = ws.shape[0]
+        w = self._to_dev(weights).reshape(-1)
+        out = torch.empty((B, 8, 5), dtype=torch.float32, device=self.device)
+        valid = torch.empty((B, 8), dtype=torch.int32, device=self.device)
+        self._call(self.lib.ocd_debug_feature_variants, self._h, _ptr(ws), _ptr(w), _ptr(out), _ptr(valid), B, self._stream())
+        self._wait()
+        return out.cpu().numpy(), valid.cpu().numpy().astype(bool)
+
     def reward_batch(self, world_state, weights):
         d = self.desc
         ws = self._in("rw_ws", world_state, (-1, d.n_cars, 4))
