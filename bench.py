@@ -699,7 +699,7 @@ def main():
                        "kernel_avg_ms": pmc["kernel_avg_us"] / 1e3, "kernel_calls": pmc["kernel_calls"],
                        "kernel_steady_avg_ms": (pmc.get("kernel_steady_avg_us") or pmc["kernel_avg_us"]) / 1e3,
                        "rule": "the profile's steady-state kernel average (later half of its dispatches) must not exceed this "
-                               "line's ms_per_step beyond box-to-box variation (2 %): tests/test_gpu_bench_contract.py"}
+                               "line's ms_per_step beyond box-to-box variation (3 %): tests/test_gpu_bench_contract.py"}
         profiled = None
         valu = {"achieved": ach_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / VALU_PEAK_TFLOPS,
                 "algorithmic_flops_per_episode": flops,

@@ -93,7 +93,7 @@ def test_bench_json_line():
     rp = rf["rocprof"]
     assert rf["kernel_symbol"] == "void ocd::mpc_kernel<10, 1, 3, 2, false, true>(ocd::KernelParams)"
     if rp["replayed"]:
-        assert rp["kernel_name"] == rf["kernel_symbol"] and rp["kernel_steady_avg_ms"] <= d["ms_per_step"] * 1.02, rp
+        assert rp["kernel_name"] == rf["kernel_symbol"] and rp["kernel_steady_avg_ms"] <= d["ms_per_step"] * 1.03, rp
         assert abs(rp["kernel_steady_avg_ms"] - rf["kernel_ms"]) <= 0.04 * rf["kernel_ms"], (rp, rf["kernel_ms"])
     else:
         assert rf["traffic"] is None and rp["why"]
