@@ -82,6 +82,21 @@ mpc_chunk_kernel(const KernelParams p)
 
     const float dt = d.dt, dt2 = d.dt_sq, fr = d.ego_friction, lr = d.learning_rate;
 
+    // the work-item list of the throughput builds' gradient passes (see horizon_pass): ITEM_CAP items of 6 (one scripted
+    // car: 8) operands, structure of arrays; the two results of an item overwrite its first two operands; slot ITEM_ZERO
+    // holds (+0, +0) for the (lane, step) pairs without the feature, beyond the last round's reach (ITEM_CAP - 1 + 63)
+#ifdef OCD_NO_ITEMS
+    constexpr bool use_items = false;
+#else
+    constexpr bool use_items = lane_feats && NO > 0 && !LAT;
+#endif
+    constexpr int ITEM_CAP = 64 * (S < 4 ? S : 4), ITEM_ZERO = ITEM_CAP + 64, ITEM_FIELDS = (NO == 1) ? 8 : 6;
+    __shared__ float item_lds[use_items ? ITEM_FIELDS : 1][use_items ? ITEM_ZERO + 1 : 1];
+    if constexpr (use_items) {
+        if (lane == 0) { item_lds[0][ITEM_ZERO] = 0.0f; item_lds[1][ITEM_ZERO] = 0.0f; }
+        __syncthreads();
+    }
+
     // ---- problem inputs (as in mpc_kernel) ----
     float ex, ey, ev, eth;
     float ox[NOA], oy[NOA], ov[NOA], oth[NOA];
@@ -410,6 +425,89 @@ mpc_chunk_kernel(const KernelParams p)
                         if (s >= SL) { q[s].qx = last ? 0.0f : q[s].qx; q[s].qy = last ? 0.0f : q[s].qy; q[s].qv = last ? 0.0f : q[s].qv; q[s].qth = last ? 0.0f : q[s].qth; }
                     }
                 }
+            } else if constexpr (use_items && GRAD) {
+                // Active features as work items (ocd_device.h: reward_base_grad / feature_item_grad): every (lane, step) pair
+                // gets the features every state has; its active fence / collision terms go to a list in LDS, are evaluated
+                // 64 at a time and come back as two adjoint terms each.  A step with two cars on one pair, beyond the guards
+                // of the shortened divisions, with a degenerate car width, under the diagnostics knobs or beyond the list's
+                // capacity evaluates every feature of every lane (reward_state), as before.
+                float x = xs, y = ys;
+                int n_items = 0;                               // wave-uniform
+                int slot_c[S], slot_f[S];
+                const float w_col = w[L + 2], w_f = w[L + 3];
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    x = x + cd[s];
+                    y = y + sd[s];
+                    const float xn = x, yn = y;
+                    const bool nf = needs_fence(d, xn);
+                    const unsigned long long lm = (s >= SL) ? real_mask : live_mask;
+                    const unsigned long long mf = __ballot(nf) & lm;
+                    unsigned long long mc_any = 0ull, multi_c = 0ull, tiny_n = 0ull;
+                    float idx = 0.0f, idy = 0.0f, iwx = 1.0f, iwy = 1.0f, irx = 1.0f, iry = 1.0f;
+#pragma unroll
+                    for (int j = 0; j < NO; ++j) {
+                        const float dx = xn - bg[s][j].cx, dy = yn - bg[s][j].cy;
+                        const bool ncj = (__builtin_fabsf(dx) < wx1[s][j]) && (__builtin_fabsf(dy) < wy1[s][j]);
+                        const unsigned long long mj = __ballot(ncj) & lm;
+                        multi_c |= (mj & mc_any);
+                        mc_any |= mj;
+                        if (j == 0) { idx = dx; idy = dy; iwx = bg[s][0].wx; iwy = bg[s][0].wy; irx = br[s][0].rx; iry = br[s][0].ry; }
+                        else { idx = ncj ? dx : idx; idy = ncj ? dy : idy; iwx = ncj ? bg[s][j].wx : iwx; iwy = ncj ? bg[s][j].wy : iwy; }
+                        if constexpr (NO == 1)                 // a zero / tiny numerator of the shortened (x - cx) / wx
+                            tiny_n |= __ballot(__builtin_fabsf(dx) < 7.888609052210118e-31f) | __ballot(__builtin_fabsf(dy) < 7.888609052210118e-31f);
+                    }
+                    const unsigned long long beyond = (__ballot(!(__builtin_fabsf(xn) < lgc.x_hi)) & mf) | (((tiny_n & mc_any) | widths_beyond) & lm);
+                    const int n_add = __popcll(mf) + __popcll(mc_any);
+                    if (full_step || p.no_unify || (multi_c | beyond) != 0ull || n_items + n_add > ITEM_CAP) {
+                        OCD_STAMP(4);
+                        rw[s] = reward_state<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], q[s], nullptr, true, true);
+                        slot_c[s] = ITEM_ZERO; slot_f[s] = ITEM_ZERO;
+                        OCD_STAMP(5); OCD_STAMP_COUNT(12);
+                    } else {
+                        rw[s] = 0.0f;
+                        reward_base_grad<L>(d, w, xn, vn[s], sn[s], cn[s], q[s], lgc, lm);
+                        const unsigned lane_bit_lo = (unsigned)lane;
+                        const bool ac = ((mc_any >> lane_bit_lo) & 1ull) != 0ull;
+                        const int ic = n_items + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mc_any >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mc_any, 0u));
+                        slot_c[s] = ac ? ic : ITEM_ZERO;
+                        if (ac) {
+                            item_lds[0][ic] = idx; item_lds[1][ic] = idy; item_lds[2][ic] = iwx; item_lds[3][ic] = iwy;
+                            item_lds[4][ic] = w_col; item_lds[5][ic] = 0.0f;
+                            if constexpr (NO == 1) { item_lds[6][ic] = irx; item_lds[7][ic] = iry; }
+                        }
+                        n_items += __popcll(mc_any);
+                        const bool af = ((mf >> lane_bit_lo) & 1ull) != 0ull;
+                        const int jf = n_items + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mf >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mf, 0u));
+                        slot_f[s] = af ? jf : ITEM_ZERO;
+                        if (af) { item_lds[0][jf] = xn; item_lds[4][jf] = w_f; item_lds[5][jf] = 1.0f; }
+                        n_items += __popcll(mf);
+                        OCD_STAMP(4);
+                    }
+                }
+                __syncthreads();                               // (one wavefront per workgroup: orders the LDS accesses)
+                for (int base = 0; base < n_items; base += 64) {
+                    const int i = base + lane;
+                    float o1, o2;
+                    const float ia = item_lds[0][i], idy_ = item_lds[1][i], iwx_ = item_lds[2][i], iwy_ = item_lds[3][i];
+                    const float iws = item_lds[4][i], ity = item_lds[5][i];
+                    float irx_ = 1.0f, iry_ = 1.0f;
+                    if constexpr (NO == 1) { irx_ = item_lds[6][i]; iry_ = item_lds[7][i]; }
+                    feature_item_grad<NO, NO == 1>(d, ity != 0.0f, ia, idy_, iwx_, iwy_, irx_, iry_, iws, pkc, o1, o2);
+                    item_lds[0][i] = o1; item_lds[1][i] = o2;
+                    OCD_STAMP_COUNT(13);
+                }
+                __syncthreads();
+                OCD_STAMP(6);
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const float c1 = item_lds[0][slot_c[s]], c2 = item_lds[1][slot_c[s]];
+                    const float f1 = item_lds[0][slot_f[s]], f2 = item_lds[1][slot_f[s]];
+                    q[s].qx = ((q[s].qx + c1) + f1) + f2;
+                    q[s].qy = q[s].qy + c2;
+                    if (s >= SL) { q[s].qx = last ? 0.0f : q[s].qx; q[s].qy = last ? 0.0f : q[s].qy; q[s].qv = last ? 0.0f : q[s].qv; q[s].qth = last ? 0.0f : q[s].qth; }
+                }
+                OCD_STAMP(7);
             } else {
                 float x = xs, y = ys;
 #pragma unroll

@@ -1017,6 +1017,165 @@ __device__ __forceinline__ float reward_one(const ocd_scenario_desc &d, const fl
     return 0.0f;
 }
 
+// ---------------------------------------------------------------- reward, active features as work items (V_CHUNK, batches)
+// The throughput builds of the chunked kernel hold S steps per lane and several wavefronts per SIMD; on BASELINE's
+// configurations about 30 % of their (lane, step) pairs have an active fence or collision feature in a given pass
+// (measured on the CPU oracle).  Instead of pushing all S x 64 pairs through reward_one's two
+// "exp(-1/u + c)" units, such a pass
+//   1. gives every pair the features every pair has (reward_base_grad: target speed, lanes, min over lanes),
+//   2. appends one WORK ITEM per active (pair, feature) to a list in LDS (prefix count over the ballot),
+//   3. evaluates the list 64 items at a time (feature_item_grad: reward_one's instruction stream on the item's operands),
+//   4. hands each pair its two adjoint terms back: q.qx = ((qx + car.o1) + fence.o1) + fence.o2, q.qy = 0 + car.o2 --
+//      the order of reward_state's sums; a pair without the feature reads (+0, +0), and x + (+-0) == x for every x
+//      but -0, which a sum that starts from +0 never is (round to nearest: (+0) + (-0) = +0, exact cancellation = +0).
+// A fence and ONE car on the same pair are two independent items (the car's share of reduce_max depends on its own
+// value only: the cars a pair does not evaluate have col == 0 exactly, see reward_one); two cars on one pair are not,
+// and such a step takes reward_state as before.
+
+// (1.) the adjoint of the features every state has; q.qy = +0.  Same operations as the head of reward_one.
+template <int L>
+__device__ __forceinline__ void reward_base_grad(const ocd_scenario_desc &d, const float (&w)[OCD_MAX_FEATURES],
+                                                 float x, float v, float sn, float cn, Q4 &q,
+                                                 const LaneGradConst<L> &lgc, const unsigned long long live_mask)
+{
+    static_assert(L > 0, "lane-feature reward only");
+    const float tgt = d.target_speed;
+    const float bound = 4.0f * (tgt * tgt);
+    const float vel = v * sn;
+    const float dv = vel - tgt;
+    const float sq = dv * dv;
+    const bool pass0 = sq <= bound;
+    const float g_sq = pass0 ? w[0] : 0.0f;
+    const float g_dv = (g_sq * 2.0f) * dv;
+    q.qv = g_dv * sn;
+    const float g_sn = g_dv * v;
+    q.qth = g_sn * cn;
+
+    float rl[L], pl[L];
+    float pmin = 0.0f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const float diff = x - d.lane_center[l];
+        rl[l] = diff * -1.0f;
+        const float d2 = rl[l] * rl[l];
+        pl[l] = d2 * 10.0f;
+        pmin = (l == 0) ? pl[0] : min_tf(pmin, pl[l]);
+    }
+    bool tie[L];
+    unsigned long long tie_two = 0ull, tie_seen = 0ull;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        tie[l] = pl[l] == pmin;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(tie[l]);
+        tie_two |= tie_seen & m;
+        tie_seen |= m;
+    }
+    float qx = 0.0f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const float g_r = (tie[l] ? lgc.g1[l] : lgc.g0[l]) * rl[l];
+        qx = qx + g_r * -1.0f;
+    }
+    if (__builtin_expect((tie_two & live_mask) != 0ull, 0)) {      // two lanes at the minimum: rare, see reward_one
+        float pm = pmin;
+        asm volatile("" : "+v"(pm));
+        int ntie_min = 0;
+#pragma unroll
+        for (int l = 0; l < L; ++l) ntie_min += (pl[l] == pm) ? 1 : 0;
+        const float min_share = inv_count(ntie_min) * w[L + 1];
+        qx = 0.0f;
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            float gl = w[1 + l];
+            gl = tie[l] ? (gl + min_share) : gl;
+            const float g_d2 = gl * 10.0f;
+            const float g_r = (g_d2 * 2.0f) * rl[l];
+            qx = qx + g_r * -1.0f;
+        }
+    }
+    q.qx = qx;
+    q.qy = 0.0f;
+}
+
+// (3.) one work item: the fence of a state (is_f: a = x, wsel = w_fence) or its collision term with ONE scripted car
+// (a = x - cx, dy = y - cy, the car's half-widths wx / wy -- with FASTZN their refined reciprocals rx / ry --,
+// wsel = w_collision).  Preconditions as reward_one<..., FASTDIV = true>: a fence item has |x| < LaneGradConst::x_hi;
+// FASTZN: widths bump_widths_guarded, |a|, |dy| >= 2^-100.  Results: fence (o1, o2) = (+-g_z, g_|x| * sign(x)),
+// car (o1, o2) = (x adjoint, y adjoint).
+template <int NO, bool FASTZN>
+__device__ __forceinline__ void feature_item_grad(const ocd_scenario_desc &d, const bool is_f, const float a, const float dy,
+                                                  const float wx, const float wy, const float rx, const float ry,
+                                                  const float wsel, const PkConsts &pkc, float &o1, float &o2)
+{
+    static_assert(!FASTZN || NO == 1, "the reciprocal form of (x - cx) / wx: one scripted car");
+    // inputs of the fence units
+    const float x = a;
+    const bool side_p = x > d.fence_lo;
+    const float z = side_p ? x : -x;
+    const float xd = z - d.fence_lo;
+    const bool pos1 = xd > 0.0f;
+    const float uf1 = d.fence_shape * (pos1 ? xd : (0.0f + 0.01f));
+    const float xd2 = d.fence_width - xd;
+    const bool pos2 = xd2 > 0.0f;
+    const float uf2 = d.fence_shape * (pos2 ? xd2 : (0.0f + 0.01f));
+    // inputs of the bump units
+    v2f ZN;
+    if constexpr (FASTZN) ZN = quot2_by_recip(v2f{a, dy}, v2f{wx, wy}, v2f{rx, ry});
+    else ZN = div2_(v2f{a, dy}, v2f{wx, wy});
+    const float znx = ZN.x, zny = ZN.y;
+    const bool condx = (znx * znx) < 1.0f;
+    const float xcx = condx ? znx : 0.0f;
+    const bool condy = (zny * zny) < 1.0f;
+    const float xcy = condy ? zny : 0.0f;
+    // the two shared units
+    const float u1 = is_f ? uf1 : (1.0f - xcx * xcx);
+    const float u2 = is_f ? uf2 : (1.0f - xcy * xcy);
+    const float addc = is_f ? 0.0f : 1.0f;
+    const v2f U = {u1, u2};
+    v2f M, Kk;
+    recip_pair_guarded(U, M, Kk);
+    const v2f E = exp_le1_2(M + splat2(addc), pkc);
+    const float m1 = M.x, m2 = M.y, e1 = E.x, e2 = E.y;
+    const float k1 = Kk.x, k2 = Kk.y;
+    // fence
+    const float F1 = pos1 ? e1 : 0.0f, F2 = pos2 ? e2 : 0.0f;
+    const float den = F1 + F2;
+    const float S = F1 / den;
+    const float ax = (x < 0.0f) ? -x : x;
+    // bumps
+    const float bxv = condx ? e1 : 0.0f;
+    const float byv = condy ? e2 : 0.0f;
+    const float pcol = bxv * byv;
+    const float col_share = ((NO == 1) ? 1.0f : ((pcol == 0.0f) ? inv_count(NO) : 1.0f)) * wsel;
+    v2f GXY;
+    {
+        const v2f B = {bxv, byv}, CS = splat2(col_share), XC = {xcx, xcy};
+        asm("v_pk_mul_f32 %[g], %[b], %[cs] op_sel:[1,0] op_sel_hi:[0,1]\n"     // (byv, bxv) * col_share
+            "v_pk_mul_f32 %[g], %[g], %[e]\n"
+            "v_pk_mul_f32 %[g], %[g], %[k]\n"
+            "v_pk_mul_f32 %[g], %[g], 2.0 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]\n"
+            "v_pk_mul_f32 %[g], %[g], %[xc]\n"
+            : [g] "=&v"(GXY) : [b] "v"(B), [cs] "v"(CS), [e] "v"(E), [k] "v"(Kk), [xc] "v"(XC));
+    }
+    const float g_znx = condx ? GXY.x : 0.0f;
+    const float g_zny = condy ? GXY.y : 0.0f;
+    const float g_Ssum = wsel * ax;
+    const float g_ax = wsel * S;
+    const v2f Q = div2_(v2f{is_f ? g_Ssum : g_znx, is_f ? -S : g_zny}, v2f{is_f ? den : wx, is_f ? den : wy});
+    const float q1 = Q.x, q2 = Q.y;
+    const float g_den = g_Ssum * q2;
+    FTape t1, t2;
+    t1.pos = pos1; t1.m = m1; t1.e = e1; t1.u = u1;
+    t2.pos = pos2; t2.m = m2; t2.e = e2; t2.u = u2;
+    const float ga = f_bwd_gated(q1, d.fence_shape, t1, k1);
+    const float gb = f_bwd_gated(g_den, d.fence_shape, t1, k1);
+    const float gc = f_bwd_gated(g_den, d.fence_shape, t2, k2);
+    const float g_z = (ga + gb) + (-gc);
+    const float sgn = (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f);
+    o1 = is_f ? (side_p ? g_z : -g_z) : q1;
+    o2 = is_f ? (g_ax * sgn) : q2;
+}
+
 // ---------------------------------------------------------------- terminal value (leaf_evaluation)
 // ValueFeature.interpolate_value (value_interpolation.py:28-61): trilinear interpolation of a value
 // table over the coarse state proj(world_state) = (x, y, v) or (x, y, v*sin(heading)); outside the grid the
