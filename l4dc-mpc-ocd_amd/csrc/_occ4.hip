@@ -44,7 +44,7 @@ namespace ocd {
 //   wavefronts per SIMD gain 4-5 % (config 4 whole 19.6 -> 18.7 ms, config 5 whole 41.0 -> 39.3 ms); smaller launches
 //   lose 3-4 % and keep the unconstrained build.  Same code, same results.
 template <int HT, int NO, int L, int S, bool LAT = false, bool OCC3 = false>
-__global__ void __launch_bounds__(64, OCC3 ? (S <= 2 ? 4 : 3) : 1) OCD_CHUNK_OCC
+__global__ void __launch_bounds__(64, OCC3 ? 4 : 1) OCD_CHUNK_OCC
 mpc_chunk_kernel(const KernelParams p)
 {
     static_assert(!(LAT && OCC3), "the latency build runs alone on its SIMD");
@@ -80,12 +80,7 @@ mpc_chunk_kernel(const KernelParams p)
     constexpr bool asm_bwd_vth = chunk_chain_supported<S, NC - 1>::bwd_vth;
 #endif
 
-    float dt = d.dt, fr = d.ego_friction;
-    const float dt2 = d.dt_sq, lr = d.learning_rate;
-    // the step length and the friction coefficient enter ~120 multiplications per pass: in the builds that share a SIMD they
-    // live in vector registers -- with an SGPR source a multiplication is a half-rate instruction beside other wavefronts
-    // (profiles/r03_issue_table.txt; config 5 whole -5 %); a wavefront alone on its SIMD issues every class at the same rate
-    if constexpr (!LAT) asm volatile("v_mov_b32 %0, %2\nv_mov_b32 %1, %3" : "=v"(dt), "=v"(fr) : "s"(d.dt), "s"(d.ego_friction));
+    const float dt = d.dt, dt2 = d.dt_sq, fr = d.ego_friction, lr = d.learning_rate;
 
     // the work-item list of the throughput builds' gradient passes (see horizon_pass): ITEM_CAP items of 6 (one scripted
     // car: 8) operands, structure of arrays; the two results of an item overwrite its first two operands; slot ITEM_ZERO
@@ -297,7 +292,7 @@ mpc_chunk_kernel(const KernelParams p)
             // speed / heading at the start of the chunk: NC-1 rounds of "walk my S steps, hand the end to the lane above"
             float vs = ev, ths = eth;
             if constexpr (asm_chains) {
-                chunk_fwd_vth<S, NC - 1, !LAT>(vs, ths, ev, eth, a_c, wdt, fr, dt, first_mask);
+                chunk_fwd_vth<S, NC - 1>(vs, ths, ev, eth, a_c, wdt, fr, dt, first_mask);
             } else {
 #pragma unroll
                 for (int r = 0; r < NC - 1; ++r) {
@@ -637,7 +632,7 @@ mpc_chunk_kernel(const KernelParams p)
                     float qva[S], qtha[S];
 #pragma unroll
                     for (int s = 0; s < S; ++s) { qva[s] = q[s].qv; qtha[s] = q[s].qth; }
-                    chunk_bwd_vth<S, NC - 1, !LAT>(LvE, LthE, qva, qtha, gA1, gv1, vpre, tau, fr, dt, last_mask);
+                    chunk_bwd_vth<S, NC - 1>(LvE, LthE, qva, qtha, gA1, gv1, vpre, tau, fr, dt, last_mask);
                 } else {
 #pragma unroll
                     for (int r = 0; r < NC - 1; ++r) {
@@ -784,9 +779,7 @@ static hipError_t launch_chunk(const KernelParams &p_in, hipStream_t st)
     p.segs_used = segs;
     const unsigned blocks = (unsigned)((p.n_problems + segs - 1) / segs);
     const bool lat = L > 0 && NO > 0 && !p.no_skips && !p.no_unify && !p.no_latency_build && (long long)blocks <= simds;
-    // (the unconstrained build of S > 2 holds two wavefronts on a SIMD: beyond two per SIMD the three-per-SIMD build keeps
-    //  them all resident; S <= 2: three resident unconstrained, four in the OCC3 build)
-    const bool occ3 = !lat && (long long)blocks > (S > 2 ? 2 : 3) * simds - (S > 2 ? 0 : 1) && !p.no_latency_build;
+    const bool occ3 = !lat && (long long)blocks >= 3 * simds && !p.no_latency_build;
     note_launch(p, 4, S, segs, blocks, lat ? 1 : (occ3 ? 3 : 0), HT, 0, 1);
     if (lat) OCD_LAUNCH((mpc_chunk_kernel<HT, NO, L, S, true>), dim3(blocks), dim3(64), 0, st, p);
     else if (occ3) OCD_LAUNCH((mpc_chunk_kernel<HT, NO, L, S, false, true>), dim3(blocks), dim3(64), 0, st, p);

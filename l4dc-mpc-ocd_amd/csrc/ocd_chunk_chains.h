@@ -61,40 +61,56 @@ template <int S, int NR> struct chunk_chain_supported {
                            OCD_VSTEP("ac3", OCD_V) OCD_VSTEP("ac4", OCD_V) OCD_FWD_VTH_TAIL
 
 // ---- forward speed / heading: on return (v, th) are the values at the START of the lane's chunk ----
-template <int S, int NR>
+// VR: fr and dt arrive in vector registers (the builds that share a SIMD: a scalar source halves the instruction's rate)
+template <int S, int NR, bool VR = false>
 __device__ __forceinline__ void chunk_fwd_vth(float &v, float &th, float ev, float eth, const float (&ac)[S],
                                               const float (&wd)[S], float fr, float dt, unsigned long long first_mask)
 {
     float thn = eth + wd[0], tmp;
     if constexpr (S == 2) {
-#define OCD_STMT(REP)                                                                                     \
+#define OCD_STMTC(REP, C)                                                                                     \
         asm volatile("s_mov_b64 vcc, %[m]\n" OCD_FWD_VTH_2("%[ev]") REP(OCD_FWD_VTH_2(OCD_V))             \
                      : [v] "=&v"(v), [th] "=&v"(th), [thn] "+&v"(thn), [t] "=&v"(tmp)                    \
                      : [ac0] "v"(ac[0]), [ac1] "v"(ac[1]), [wd0] "v"(wd[0]), [wd1] "v"(wd[1]), [ev] "v"(ev), \
-                       [eth] "v"(eth), [fr] "s"(fr), [dt] "s"(dt), [m] "s"(first_mask)                    \
+                       [eth] "v"(eth), [fr] C(fr), [dt] C(dt), [m] "s"(first_mask)                    \
                      : "vcc");
-        OCD_CHUNK_ROUNDS_M1(NR, OCD_STMT);
+#define OCD_STMT(REP) OCD_STMTC(REP, "v")
+        if constexpr (VR) { OCD_CHUNK_ROUNDS_M1(NR, OCD_STMT); }
 #undef OCD_STMT
+#define OCD_STMT(REP) OCD_STMTC(REP, "s")
+        if constexpr (!VR) { OCD_CHUNK_ROUNDS_M1(NR, OCD_STMT); }
+#undef OCD_STMT
+#undef OCD_STMTC
     } else if constexpr (S == 3) {
-#define OCD_STMT(REP)                                                                                     \
+#define OCD_STMTC(REP, C)                                                                                     \
         asm volatile("s_mov_b64 vcc, %[m]\n" OCD_FWD_VTH_3("%[ev]") REP(OCD_FWD_VTH_3(OCD_V))             \
                      : [v] "=&v"(v), [th] "=&v"(th), [thn] "+&v"(thn), [t] "=&v"(tmp)                    \
                      : [ac0] "v"(ac[0]), [ac1] "v"(ac[1]), [ac2] "v"(ac[2]), [wd0] "v"(wd[0]), [wd1] "v"(wd[1]), \
-                       [wd2] "v"(wd[2]), [ev] "v"(ev), [eth] "v"(eth), [fr] "s"(fr), [dt] "s"(dt), [m] "s"(first_mask) \
+                       [wd2] "v"(wd[2]), [ev] "v"(ev), [eth] "v"(eth), [fr] C(fr), [dt] C(dt), [m] "s"(first_mask) \
                      : "vcc");
-        OCD_CHUNK_ROUNDS_M1(NR, OCD_STMT);
+#define OCD_STMT(REP) OCD_STMTC(REP, "v")
+        if constexpr (VR) { OCD_CHUNK_ROUNDS_M1(NR, OCD_STMT); }
 #undef OCD_STMT
+#define OCD_STMT(REP) OCD_STMTC(REP, "s")
+        if constexpr (!VR) { OCD_CHUNK_ROUNDS_M1(NR, OCD_STMT); }
+#undef OCD_STMT
+#undef OCD_STMTC
     } else {
         static_assert(S == 5, "chunk sizes 2, 3, 5");
-#define OCD_STMT(REP)                                                                                     \
+#define OCD_STMTC(REP, C)                                                                                     \
         asm volatile("s_mov_b64 vcc, %[m]\n" OCD_FWD_VTH_5("%[ev]") REP(OCD_FWD_VTH_5(OCD_V))             \
                      : [v] "=&v"(v), [th] "=&v"(th), [thn] "+&v"(thn), [t] "=&v"(tmp)                    \
                      : [ac0] "v"(ac[0]), [ac1] "v"(ac[1]), [ac2] "v"(ac[2]), [ac3] "v"(ac[3]), [ac4] "v"(ac[4]), \
                        [wd0] "v"(wd[0]), [wd1] "v"(wd[1]), [wd2] "v"(wd[2]), [wd3] "v"(wd[3]), [wd4] "v"(wd[4]), \
-                       [ev] "v"(ev), [eth] "v"(eth), [fr] "s"(fr), [dt] "s"(dt), [m] "s"(first_mask)      \
+                       [ev] "v"(ev), [eth] "v"(eth), [fr] C(fr), [dt] C(dt), [m] "s"(first_mask)      \
                      : "vcc");
-        OCD_CHUNK_ROUNDS_M1(NR, OCD_STMT);
+#define OCD_STMT(REP) OCD_STMTC(REP, "v")
+        if constexpr (VR) { OCD_CHUNK_ROUNDS_M1(NR, OCD_STMT); }
 #undef OCD_STMT
+#define OCD_STMT(REP) OCD_STMTC(REP, "s")
+        if constexpr (!VR) { OCD_CHUNK_ROUNDS_M1(NR, OCD_STMT); }
+#undef OCD_STMT
+#undef OCD_STMTC
     }
 }
 
@@ -227,7 +243,7 @@ __device__ __forceinline__ void chunk_bwd_xy(float &Lx, float &Ly, const float (
                           OCD_LVSTEP("2", LV) OCD_LVSTEP("1", OCD_LV) OCD_LVSTEP("0", OCD_LV) OCD_BWD_VTH_TAIL("2")
 
 // ---- adjoint speed / heading: on return (Lv, Lth) are the adjoint arriving at the END of the lane's chunk ----
-template <int S, int NR>
+template <int S, int NR, bool VR = false>
 __device__ __forceinline__ void chunk_bwd_vth(float &Lv, float &Lth, const float (&qv)[S], const float (&qth)[S],
                                               const float (&gA1)[S], const float (&gv1)[S], const float (&vp)[S],
                                               const float (&tau)[S], float fr, float dt, unsigned long long last_mask)
@@ -235,29 +251,39 @@ __device__ __forceinline__ void chunk_bwd_vth(float &Lv, float &Lth, const float
     float ltd = (qth[S - 1] + 0.0f) + tau[S - 1], av, s, g;
     const float zero = 0.0f;
     if constexpr (S == 2) {
-#define OCD_STMT(REP)                                                                                     \
+#define OCD_STMTC(REP, C)                                                                                     \
         asm volatile("s_mov_b64 vcc, %[m]\n" OCD_BWD_VTH_2("0") REP(OCD_BWD_VTH_2(OCD_LV))                \
                      : [Lv] "=&v"(Lv), [Lth] "=&v"(Lth), [ltd] "+&v"(ltd), [av] "=&v"(av), [s] "=&v"(s), [g] "=&v"(g) \
                      : [qv0] "v"(qv[0]), [qv1] "v"(qv[1]), [qth0] "v"(qth[0]), [qth1] "v"(qth[1]),        \
                        [gA10] "v"(gA1[0]), [gA11] "v"(gA1[1]), [gv10] "v"(gv1[0]), [gv11] "v"(gv1[1]),    \
                        [vp0] "v"(vp[0]), [vp1] "v"(vp[1]), [tau0] "v"(tau[0]), [tau1] "v"(tau[1]),        \
-                       [z] "v"(zero), [fr] "s"(fr), [dt] "s"(dt), [m] "s"(last_mask)                      \
+                       [z] "v"(zero), [fr] C(fr), [dt] C(dt), [m] "s"(last_mask)                      \
                      : "vcc");
-        OCD_CHUNK_ROUNDS_M1(NR, OCD_STMT);
+#define OCD_STMT(REP) OCD_STMTC(REP, "v")
+        if constexpr (VR) { OCD_CHUNK_ROUNDS_M1(NR, OCD_STMT); }
 #undef OCD_STMT
+#define OCD_STMT(REP) OCD_STMTC(REP, "s")
+        if constexpr (!VR) { OCD_CHUNK_ROUNDS_M1(NR, OCD_STMT); }
+#undef OCD_STMT
+#undef OCD_STMTC
     } else {
         static_assert(S == 3, "adjoint speed / heading chain: chunk sizes 2 and 3");
-#define OCD_STMT(REP)                                                                                     \
+#define OCD_STMTC(REP, C)                                                                                     \
         asm volatile("s_mov_b64 vcc, %[m]\n" OCD_BWD_VTH_3("0") REP(OCD_BWD_VTH_3(OCD_LV))                \
                      : [Lv] "=&v"(Lv), [Lth] "=&v"(Lth), [ltd] "+&v"(ltd), [av] "=&v"(av), [s] "=&v"(s), [g] "=&v"(g) \
                      : [qv0] "v"(qv[0]), [qv1] "v"(qv[1]), [qv2] "v"(qv[2]), [qth0] "v"(qth[0]), [qth1] "v"(qth[1]), \
                        [qth2] "v"(qth[2]), [gA10] "v"(gA1[0]), [gA11] "v"(gA1[1]), [gA12] "v"(gA1[2]),    \
                        [gv10] "v"(gv1[0]), [gv11] "v"(gv1[1]), [gv12] "v"(gv1[2]), [vp0] "v"(vp[0]), [vp1] "v"(vp[1]), \
                        [vp2] "v"(vp[2]), [tau0] "v"(tau[0]), [tau1] "v"(tau[1]), [tau2] "v"(tau[2]),      \
-                       [z] "v"(zero), [fr] "s"(fr), [dt] "s"(dt), [m] "s"(last_mask)                      \
+                       [z] "v"(zero), [fr] C(fr), [dt] C(dt), [m] "s"(last_mask)                      \
                      : "vcc");
-        OCD_CHUNK_ROUNDS_M1(NR, OCD_STMT);
+#define OCD_STMT(REP) OCD_STMTC(REP, "v")
+        if constexpr (VR) { OCD_CHUNK_ROUNDS_M1(NR, OCD_STMT); }
 #undef OCD_STMT
+#define OCD_STMT(REP) OCD_STMTC(REP, "s")
+        if constexpr (!VR) { OCD_CHUNK_ROUNDS_M1(NR, OCD_STMT); }
+#undef OCD_STMT
+#undef OCD_STMTC
     }
 }
 
