@@ -99,7 +99,10 @@ mpc_chunk_kernel(const KernelParams p)
     constexpr bool use_items = lane_feats && NO > 0 && !LAT;
 #endif
 #endif
-    constexpr int ITEM_CAP = 64 * (S < 4 ? S : 4), ITEM_ZERO = ITEM_CAP + 64, ITEM_FIELDS = (NO == 1) ? 8 : 6;
+    constexpr int ITEM_CAP = 64 * (S < 4 ? S : 4), ITEM_ZERO = ITEM_CAP + 64, ITEM_FIELDS = (NO == 1) ? 8 : 6, ITEM_PAIR_BIT = 1 << 16;
+    // a state inside BOTH cars' boxes as a pair of items: the builds with room for it (measured: replanning H = 15 at S = 3
+    // -5.6 %; at S = 5 the extra paths cost the three-per-SIMD build of merging H = 25 +14 %: there such a step takes reward_state)
+    constexpr bool pair_items = NO == 2 && S <= 3;
     __shared__ float item_lds[use_items ? ITEM_FIELDS : 1][use_items ? ITEM_ZERO + 1 : 1];
     if constexpr (use_items) {
         if (lane == 0) { item_lds[0][ITEM_ZERO] = 0.0f; item_lds[1][ITEM_ZERO] = 0.0f; }
@@ -437,12 +440,14 @@ mpc_chunk_kernel(const KernelParams p)
             } else if constexpr (use_items && GRAD) {
                 // Active features as work items (ocd_device.h: reward_base_grad / feature_item_grad): every (lane, step) pair
                 // gets the features every state has; its active fence / collision terms go to a list in LDS, are evaluated
-                // 64 at a time and come back as two adjoint terms each.  A step with two cars on one pair, beyond the guards
-                // of the shortened divisions, with a degenerate car width, under the diagnostics knobs or beyond the list's
-                // capacity evaluates every feature of every lane (reward_state), as before.
+                // 64 at a time and come back as two adjoint terms each.  A state inside BOTH cars' boxes appends its two
+                // collision items side by side at an even slot (the evaluation compares the two lanes' products).  A step
+                // beyond the guards of the shortened divisions, with a degenerate car width, under the diagnostics knobs or
+                // beyond the list's capacity evaluates every feature of every lane (reward_state), as before.
                 float x = xs, y = ys;
                 int n_items = 0;                               // wave-uniform
-                int slot_c[S], slot_f[S];
+                bool any_pair = false;                         // wave-uniform: some state of this pass is inside both boxes
+                int slot_c[S], slot_f[S];                      // (slot_c of such a state: its first item | ITEM_PAIR_BIT)
                 const float w_col = w[L + 2], w_f = w[L + 3];
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
@@ -454,8 +459,9 @@ mpc_chunk_kernel(const KernelParams p)
                     const unsigned long long mf = __ballot(nf) & lm;
                     unsigned long long mc_any = 0ull, multi_c = 0ull, tiny_n = 0ull;
                     float idx = 0.0f, idy = 0.0f, iwx = 1.0f, iwy = 1.0f, irx = 1.0f, iry = 1.0f;
+                    float dxl[NOA], dyl[NOA];
                     const bool in_lm = (s >= SL) ? (live && !last) : live;        // this lane's bit of lm
-                    bool nc_any = false;
+                    bool nc_any = false, nc_both = false;
 #pragma unroll
                     for (int j = 0; j < NO; ++j) {
                         const float dx = xn - bg[s][j].cx, dy = yn - bg[s][j].cy;
@@ -463,15 +469,17 @@ mpc_chunk_kernel(const KernelParams p)
                         const unsigned long long mj = __ballot(ncj) & lm;
                         multi_c |= (mj & mc_any);
                         mc_any |= mj;
+                        nc_both = nc_both || (nc_any && ncj);
                         nc_any = nc_any || ncj;
+                        dxl[j] = dx; dyl[j] = dy;
                         if (j == 0) { idx = dx; idy = dy; iwx = bg[s][0].wx; iwy = bg[s][0].wy; irx = br[s][0].rx; iry = br[s][0].ry; }
                         else { idx = ncj ? dx : idx; idy = ncj ? dy : idy; iwx = ncj ? bg[s][j].wx : iwx; iwy = ncj ? bg[s][j].wy : iwy; }
                         if constexpr (NO == 1)                 // a zero / tiny numerator of the shortened (x - cx) / wx
                             tiny_n |= __ballot(__builtin_fabsf(dx) < 7.888609052210118e-31f) | __ballot(__builtin_fabsf(dy) < 7.888609052210118e-31f);
                     }
                     const unsigned long long beyond = (__ballot(!(__builtin_fabsf(xn) < lgc.x_hi)) & mf) | (((tiny_n & mc_any) | widths_beyond) & lm);
-                    const int n_add = __popcll(mf) + __popcll(mc_any);
-                    if (full_step || p.no_unify || (multi_c | beyond) != 0ull || n_items + n_add > ITEM_CAP) {
+                    const int n_add = __popcll(mf) + __popcll(mc_any) + (pair_items ? __popcll(multi_c) + 1 : 0);
+                    if (full_step || p.no_unify || beyond != 0ull || (!pair_items && multi_c != 0ull) || n_items + n_add > ITEM_CAP) {
                         OCD_STAMP(4);
                         rw[s] = reward_state<NO, L, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], q[s], nullptr, true, true);
                         slot_c[s] = ITEM_ZERO; slot_f[s] = ITEM_ZERO;
@@ -479,15 +487,41 @@ mpc_chunk_kernel(const KernelParams p)
                     } else {
                         rw[s] = 0.0f;
                         reward_base_grad<L>(d, w, xn, vn[s], sn[s], cn[s], q[s], lgc, lm);
-                        const bool ac = nc_any && in_lm;
-                        const int ic = n_items + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mc_any >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mc_any, 0u));
-                        slot_c[s] = ac ? ic : ITEM_ZERO;
-                        if (ac) {
-                            item_lds[0][ic] = idx; item_lds[1][ic] = idy; item_lds[2][ic] = iwx; item_lds[3][ic] = iwy;
-                            item_lds[4][ic] = w_col; item_lds[5][ic] = 0.0f;
-                            if constexpr (NO == 1) { item_lds[6][ic] = irx; item_lds[7][ic] = iry; }
+                        if (pair_items && __builtin_expect(multi_c != 0ull, 0)) {
+                            // some state is inside both boxes: the single items first, then the pairs from an even slot
+                            const unsigned long long ms = mc_any & ~multi_c;
+                            const bool ac = nc_any && !nc_both && in_lm;
+                            const int ic = n_items + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ms >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ms, 0u));
+                            if (ac) {
+                                item_lds[0][ic] = idx; item_lds[1][ic] = idy; item_lds[2][ic] = iwx; item_lds[3][ic] = iwy;
+                                item_lds[4][ic] = w_col; item_lds[5][ic] = 0.0f;
+                            }
+                            n_items += __popcll(ms);
+                            n_items += n_items & 1;
+                            const bool ad = nc_both && in_lm;
+                            const int id = n_items + 2 * (int)__builtin_amdgcn_mbcnt_hi((unsigned)(multi_c >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)multi_c, 0u));
+                            if (ad) {
+#pragma unroll
+                                for (int j = 0; j < (pair_items ? 2 : 0); ++j) {
+                                    item_lds[0][id + j] = dxl[j]; item_lds[1][id + j] = dyl[j];
+                                    item_lds[2][id + j] = bg[s][j].wx; item_lds[3][id + j] = bg[s][j].wy;
+                                    item_lds[4][id + j] = w_col; item_lds[5][id + j] = 2.0f;
+                                }
+                            }
+                            n_items += 2 * __popcll(multi_c);
+                            slot_c[s] = ad ? (id | ITEM_PAIR_BIT) : (ac ? ic : ITEM_ZERO);
+                            any_pair = true;
+                        } else {
+                            const bool ac = nc_any && in_lm;
+                            const int ic = n_items + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mc_any >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mc_any, 0u));
+                            slot_c[s] = ac ? ic : ITEM_ZERO;
+                            if (ac) {
+                                item_lds[0][ic] = idx; item_lds[1][ic] = idy; item_lds[2][ic] = iwx; item_lds[3][ic] = iwy;
+                                item_lds[4][ic] = w_col; item_lds[5][ic] = 0.0f;
+                                if constexpr (NO == 1) { item_lds[6][ic] = irx; item_lds[7][ic] = iry; }
+                            }
+                            n_items += __popcll(mc_any);
                         }
-                        n_items += __popcll(mc_any);
                         const bool af = nf && in_lm;
                         const int jf = n_items + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mf >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mf, 0u));
                         slot_f[s] = af ? jf : ITEM_ZERO;
@@ -504,19 +538,38 @@ mpc_chunk_kernel(const KernelParams p)
                     const float iws = item_lds[4][i], ity = item_lds[5][i];
                     float irx_ = 1.0f, iry_ = 1.0f;
                     if constexpr (NO == 1) { irx_ = item_lds[6][i]; iry_ = item_lds[7][i]; }
-                    feature_item_grad<NO, NO == 1>(d, ity != 0.0f, ia, idy_, iwx_, iwy_, irx_, iry_, iws, pkc, o1, o2);
+                    if (pair_items && __builtin_expect(any_pair, 0))
+                        feature_item_grad<NO, NO == 1>(d, ity == 1.0f, ity == 2.0f, ia, idy_, iwx_, iwy_, irx_, iry_, iws, pkc, o1, o2);
+                    else
+                        feature_item_grad<NO, NO == 1>(d, ity == 1.0f, false, ia, idy_, iwx_, iwy_, irx_, iry_, iws, pkc, o1, o2);
                     item_lds[0][i] = o1; item_lds[1][i] = o2;
                     OCD_STAMP_COUNT(13);
                 }
                 __syncthreads();
                 OCD_STAMP(6);
+                if (pair_items && __builtin_expect(any_pair, 0)) {
+                    // reduce_max's gradient of a state inside both boxes: car 0's terms, then car 1's (reward_state's order)
 #pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    const float c1 = item_lds[0][slot_c[s]], c2 = item_lds[1][slot_c[s]];
-                    const float f1 = item_lds[0][slot_f[s]], f2 = item_lds[1][slot_f[s]];
-                    q[s].qx = ((q[s].qx + c1) + f1) + f2;
-                    q[s].qy = q[s].qy + c2;
-                    if (s >= SL) { q[s].qx = last ? 0.0f : q[s].qx; q[s].qy = last ? 0.0f : q[s].qy; q[s].qv = last ? 0.0f : q[s].qv; q[s].qth = last ? 0.0f : q[s].qth; }
+                    for (int s = 0; s < S; ++s) {
+                        const bool pr = (slot_c[s] & ITEM_PAIR_BIT) != 0;
+                        const int sc = slot_c[s] & (ITEM_PAIR_BIT - 1), sd2 = pr ? sc + 1 : ITEM_ZERO;
+                        const float c1 = item_lds[0][sc], c2 = item_lds[1][sc], d1 = item_lds[0][sd2], d2 = item_lds[1][sd2];
+                        const float f1 = item_lds[0][slot_f[s]], f2 = item_lds[1][slot_f[s]];
+                        q[s].qx = (((q[s].qx + c1) + d1) + f1) + f2;
+                        q[s].qy = (q[s].qy + c2) + d2;
+                    }
+                } else {
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        const float c1 = item_lds[0][slot_c[s]], c2 = item_lds[1][slot_c[s]];
+                        const float f1 = item_lds[0][slot_f[s]], f2 = item_lds[1][slot_f[s]];
+                        q[s].qx = ((q[s].qx + c1) + f1) + f2;
+                        q[s].qy = q[s].qy + c2;
+                    }
+                }
+                if constexpr (SL < S) {
+#pragma unroll
+                    for (int s = SL; s < S; ++s) { q[s].qx = last ? 0.0f : q[s].qx; q[s].qy = last ? 0.0f : q[s].qy; q[s].qv = last ? 0.0f : q[s].qv; q[s].qth = last ? 0.0f : q[s].qth; }
                 }
                 OCD_STAMP(7);
             } else {

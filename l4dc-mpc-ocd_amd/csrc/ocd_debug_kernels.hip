@@ -7,6 +7,9 @@
 //                  shortened divisions; one scripted car: also (x - cx) / wx by the control step's reciprocals)
 //   reward_fc      fence + at most one car per lane, two packed pairs (full / shortened)
 //   reward_fcc     fence + both cars (two scripted cars), three packed pairs (full / shortened)   [through reward_every]
+//   work items     reward_base_grad + one feature_item_grad per active (state, feature), compacted through LDS and evaluated
+//                  64 at a time -- the gradient passes of the chunked kernel's shared-SIMD builds; a state inside both
+//                  cars' boxes as a pair of neighbouring items (adjoint only; one or two scripted cars)
 // The planner tests reach them through whole plans; this kernel evaluates ALL of them on caller-supplied world states, one
 // state per lane, and says per lane which forms' preconditions hold -- tests/test_gpu_feature_variants.py holds every
 // valid (state, form) pair to reward_state's value and adjoint, bit for bit, so a change of the contract (or another
@@ -20,7 +23,7 @@
 
 namespace ocd {
 
-enum { FV_VARIANTS = 8, FV_VALUES = 5 };   // (r, qx, qy, qv, qth) per form
+enum { FV_VARIANTS = 9, FV_VALUES = 5 };   // (r, qx, qy, qv, qth) per form
 
 template <int NO, int L>
 __global__ void __launch_bounds__(64) feature_variants_kernel(const KernelParams p, float *out, int32_t *valid)
@@ -97,6 +100,67 @@ __global__ void __launch_bounds__(64) feature_variants_kernel(const KernelParams
     res[7][0] = res[6][0];
     (void)reward_every<NO, L, true, true>(d, w, x, y, v, sn, cn, bg, q, pkc, &lgc, live_mask);
     res[7][1] = q.qx; res[7][2] = q.qy; res[7][3] = q.qv; res[7][4] = q.qth; ok[7] = guard_f && !degenerate;
+    // 8: the work-item form (mpc_chunk_kernel's gradient passes, same list layout: singles, pairs from an even slot, fences)
+    res[8][0] = res[0][0];
+    ok[8] = false;
+    if constexpr (NO <= 2) {
+        constexpr int ZERO = 3 * 64 + 64, FIELDS = (NO == 1) ? 8 : 6;
+        __shared__ float item_lds[FIELDS][ZERO + 1];
+        if (threadIdx.x == 0) { item_lds[0][ZERO] = 0.0f; item_lds[1][ZERO] = 0.0f; }
+        __syncthreads();
+        reward_base_grad<L>(d, w, x, v, sn, cn, q, lgc, live_mask);
+        const bool both = n_in == 2, single = n_in == 1;
+        int jc = 0;
+#pragma unroll
+        for (int j = 1; j < NO; ++j) jc = nc[j] ? j : jc;
+        const unsigned long long ms = __ballot(single && live), mp = __ballot(both && live), mf = __ballot(nf && live);
+        int n_items = 0, slot_c = ZERO, slot_d = ZERO, slot_f = ZERO;
+        if (single && live) {
+            const int ic = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ms >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ms, 0u));
+            item_lds[0][ic] = x - bg[jc].cx; item_lds[1][ic] = y - bg[jc].cy; item_lds[2][ic] = bg[jc].wx; item_lds[3][ic] = bg[jc].wy;
+            item_lds[4][ic] = w[L + 2]; item_lds[5][ic] = 0.0f;
+            if constexpr (NO == 1) { item_lds[6][ic] = br[0].rx; item_lds[7][ic] = br[0].ry; }
+            slot_c = ic;
+        }
+        n_items += __popcll(ms);
+        n_items += n_items & 1;
+        if constexpr (NO == 2) {
+            if (both && live) {
+                const int id = n_items + 2 * (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mp >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mp, 0u));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    item_lds[0][id + j] = x - bg[j].cx; item_lds[1][id + j] = y - bg[j].cy;
+                    item_lds[2][id + j] = bg[j].wx; item_lds[3][id + j] = bg[j].wy; item_lds[4][id + j] = w[L + 2]; item_lds[5][id + j] = 2.0f;
+                }
+                slot_c = id; slot_d = id + 1;
+            }
+            n_items += 2 * __popcll(mp);
+        }
+        if (nf && live) {
+            const int jf = n_items + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mf >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mf, 0u));
+            item_lds[0][jf] = x; item_lds[4][jf] = w[L + 3]; item_lds[5][jf] = 1.0f;
+            slot_f = jf;
+        }
+        n_items += __popcll(mf);
+        __syncthreads();
+        for (int base = 0; base < n_items; base += 64) {
+            const int i = base + (int)threadIdx.x;
+            float o1, o2, irx = 1.0f, iry = 1.0f;
+            const float ia = item_lds[0][i], idy = item_lds[1][i], iwx = item_lds[2][i], iwy = item_lds[3][i], iws = item_lds[4][i], ity = item_lds[5][i];
+            if constexpr (NO == 1) { irx = item_lds[6][i]; iry = item_lds[7][i]; }
+            feature_item_grad<NO, NO == 1>(d, ity == 1.0f, ity == 2.0f, ia, idy, iwx, iwy, irx, iry, iws, pkc, o1, o2);
+            item_lds[0][i] = o1; item_lds[1][i] = o2;
+        }
+        __syncthreads();
+        const float c1 = item_lds[0][slot_c], c2 = item_lds[1][slot_c], d1 = item_lds[0][slot_d], d2 = item_lds[1][slot_d];
+        const float f1 = item_lds[0][slot_f], f2 = item_lds[1][slot_f];
+        res[8][1] = (((q.qx + c1) + d1) + f1) + f2; res[8][2] = (q.qy + c2) + d2; res[8][3] = q.qv; res[8][4] = q.qth;
+        // (a lane outside the guards spoils only its own items)
+        ok[8] = guard_f && !degenerate && (!ZN || (widths_ok && !tiny));
+    } else {
+#pragma unroll
+        for (int c = 1; c < FV_VALUES; ++c) res[8][c] = 0.0f;
+    }
     if (!live) return;
 #pragma unroll
     for (int k = 0; k < FV_VARIANTS; ++k) {

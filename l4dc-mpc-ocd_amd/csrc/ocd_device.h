@@ -485,6 +485,7 @@ __device__ __forceinline__ float reward_fc(const ocd_scenario_desc &d, const flo
     }
     const v2f EB = exp_le1_2(MB + splat2(1.0f), pkc), EF = exp_le1_2(MF, pkc);
     const float mb1 = MB.x, mb2 = MB.y, mf1 = MF.x, mf2 = MF.y, eb1 = EB.x, eb2 = EB.y, ef1 = EF.x, ef2 = EF.y;
+    (void)mb1; (void)mb2;
 #endif
     const float bxv = condx ? eb1 : 0.0f;
     const float byv = condy ? eb2 : 0.0f;
@@ -1102,12 +1103,17 @@ __device__ __forceinline__ void reward_base_grad(const ocd_scenario_desc &d, con
 // wsel = w_collision).  Preconditions as reward_one<..., FASTDIV = true>: a fence item has |x| < LaneGradConst::x_hi;
 // FASTZN: widths bump_widths_guarded, |a|, |dy| >= 2^-100.  Results: fence (o1, o2) = (+-g_z, g_|x| * sign(x)),
 // car (o1, o2) = (x adjoint, y adjoint).
+// is_pair (two scripted cars): the state is inside BOTH cars' boxes and its two collision items sit in neighbouring lanes
+// (even / odd); each lane evaluates its own car, and the share of reduce_max's gradient (merging.py:78) comes from comparing
+// the two products: the larger takes w_collision, equal ones half each, the smaller exactly 0 -- reward_state's
+// (col == max ? w / ties : 0).  A single item's other car has col == 0 exactly (see reward_one).
 template <int NO, bool FASTZN>
-__device__ __forceinline__ void feature_item_grad(const ocd_scenario_desc &d, const bool is_f, const float a, const float dy,
-                                                  const float wx, const float wy, const float rx, const float ry,
+__device__ __forceinline__ void feature_item_grad(const ocd_scenario_desc &d, const bool is_f, const bool is_pair, const float a,
+                                                  const float dy, const float wx, const float wy, const float rx, const float ry,
                                                   const float wsel, const PkConsts &pkc, float &o1, float &o2)
 {
     static_assert(!FASTZN || NO == 1, "the reciprocal form of (x - cx) / wx: one scripted car");
+    static_assert(NO <= 2, "reduce_max over at most two scripted cars");
     // inputs of the fence units
     const float x = a;
     const bool side_p = x > d.fence_lo;
@@ -1146,7 +1152,16 @@ __device__ __forceinline__ void feature_item_grad(const ocd_scenario_desc &d, co
     const float bxv = condx ? e1 : 0.0f;
     const float byv = condy ? e2 : 0.0f;
     const float pcol = bxv * byv;
-    const float col_share = ((NO == 1) ? 1.0f : ((pcol == 0.0f) ? inv_count(NO) : 1.0f)) * wsel;
+    float col_share;
+    if constexpr (NO == 1) {
+        col_share = 1.0f * wsel;
+    } else {
+        // the neighbouring lane's product (quad_perm [1, 0, 3, 2]); 0 for a single item
+        const float nb = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(pcol), 0xB1, 0xf, 0xf, true));
+        const float other = is_pair ? nb : 0.0f;
+        const float part = (pcol == other) ? inv_count(2) : 1.0f;
+        col_share = (pcol < other) ? 0.0f : (part * wsel);
+    }
     v2f GXY;
     {
         const v2f B = {bxv, byv}, CS = splat2(col_share), XC = {xcx, xcy};
