@@ -15,9 +15,17 @@
 //     lane, at full lane utilisation -- it becomes 80 % of a pass, which is what the algorithm needs.
 //
 // ONE wavefront per workgroup; segment (j, k) = trajectory j, initialisation k; the first-index argmin
-// over the K initialisations is taken inside the wavefront (ds_bpermute), no LDS, no barrier.
+// over the K initialisations is taken inside the wavefront (ds_bpermute).
 // Sums keep the reference's sequential order (the chunk's partial value travels up / down the segment),
 // so results are bit-identical to the other variants and to the oracle.
+//
+// The builds that share a SIMD with other wavefronts (round 5): a wavefront holds S x 64 (lane, step) pairs and on
+// BASELINE's configurations about 30 % of them have an active fence / collision feature in a given pass, so the gradient
+// passes do not push every pair through the two "exp(-1/u + c)" units: the active (pair, feature) terms go to a
+// work-item list in LDS (6-10 KB per wavefront), are evaluated 64 at a time and come back as two adjoint terms each
+// (horizon_pass; ocd_device.h: reward_base_grad / feature_item_grad).  Config 5 whole 37.6 -> 30.8 ms, config 4 whole
+// 18.2 -> 14.2 ms, 16 x config 3 13.4 -> 11.7 ms (profiles/r05_items_ab.txt).  A wavefront alone on its SIMD (LAT) keeps
+// the straight-line evaluation of every pair: there the list's LDS round trips are not hidden (measured: +-0 ... +20 %).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -40,9 +48,10 @@ namespace ocd {
 //   also claims its SIMD (see the a255 clobber below).
 //   The diagnostics knobs no_feature_skips / no_unified_features select the LAT = false build.
 // OCC3: compiled for THREE wavefronts per SIMD (<= 168 VGPRs; hipcc spills 20-70 dwords of the per-step tape to
-//   scratch, which three wavefronts hide) -- FOUR (128 VGPRs) for S <= 2: launches with at least three full-packed
-//   wavefronts per SIMD gain 4-5 % (config 4 whole 19.6 -> 18.7 ms, config 5 whole 41.0 -> 39.3 ms); smaller launches
-//   lose 3-4 % and keep the unconstrained build.  Same code, same results.
+//   scratch, which three wavefronts hide) -- FOUR (128 VGPRs) for S <= 2: launches with more wavefronts than the
+//   unconstrained build keeps resident (two per SIMD at S > 2, three at S <= 2) take it: config 4 whole 19.6 -> 18.7 ms,
+//   config 5 whole 41.0 -> 39.3 ms in round 3; 24 576 / 28 672 episodes of config 3's shape at S = 5: 10.5 -> 9.0 ms,
+//   10.4 -> 9.0 ms in round 5; smaller launches lose 3-4 % and keep the unconstrained build.  Same code, same results.
 template <int HT, int NO, int L, int S, bool LAT = false, bool OCC3 = false>
 __global__ void __launch_bounds__(64, OCC3 ? (S <= 2 ? 4 : 3) : 1) OCD_CHUNK_OCC
 mpc_chunk_kernel(const KernelParams p)
@@ -93,11 +102,7 @@ mpc_chunk_kernel(const KernelParams p)
 #ifdef OCD_NO_ITEMS
     constexpr bool use_items = false;
 #else
-#ifdef OCD_ITEMS_LAT
-    constexpr bool use_items = lane_feats && NO > 0;
-#else
     constexpr bool use_items = lane_feats && NO > 0 && !LAT;
-#endif
 #endif
     constexpr int ITEM_CAP = 64 * (S < 4 ? S : 4), ITEM_ZERO = ITEM_CAP + 64, ITEM_FIELDS = (NO == 1) ? 8 : 6, ITEM_PAIR_BIT = 1 << 16;
     // a state inside BOTH cars' boxes as a pair of items: the builds with room for it (measured: replanning H = 15 at S = 3
