@@ -96,21 +96,24 @@ mpc_chunk_kernel(const KernelParams p)
     // (profiles/r03_issue_table.txt; config 5 whole -5 %); a wavefront alone on its SIMD issues every class at the same rate
     if constexpr (!LAT) asm volatile("v_mov_b32 %0, %2\nv_mov_b32 %1, %3" : "=v"(dt), "=v"(fr) : "s"(d.dt), "s"(d.ego_friction));
 
-    // the work-item list of the throughput builds' gradient passes (see horizon_pass): ITEM_CAP items of 6 (one scripted
-    // car: 8) operands, structure of arrays; the two results of an item overwrite its first two operands; slot ITEM_ZERO
-    // holds (+0, +0) for the (lane, step) pairs without the feature, beyond the last round's reach (ITEM_CAP - 1 + 63)
+    // the work-item list of the shared-SIMD builds' gradient passes (see horizon_pass): ITEM_CAP items of 6 (one scripted
+    // car: 8) operands -- four operands, a (weight, kind) pair that the item's two results overwrite, and the pair of
+    // reciprocals; slot ITEM_ZERO holds (+0, +0) for the (lane, step) pairs without the feature, beyond the last round's
+    // reach (ITEM_CAP - 1 + 63)
 #ifdef OCD_NO_ITEMS
     constexpr bool use_items = false;
 #else
     constexpr bool use_items = lane_feats && NO > 0 && !LAT;
 #endif
-    constexpr int ITEM_CAP = 64 * (S < 4 ? S : 4), ITEM_ZERO = ITEM_CAP + 64, ITEM_FIELDS = (NO == 1) ? 8 : 6, ITEM_PAIR_BIT = 1 << 16;
+    constexpr int ITEM_CAP = 64 * (S < 4 ? S : 4), ITEM_ZERO = ITEM_CAP + 64, ITEM_PAIR_BIT = 1 << 16;
     // a state inside BOTH cars' boxes as a pair of items: the builds with room for it (measured: replanning H = 15 at S = 3
     // -5.6 %; at S = 5 the extra paths cost the three-per-SIMD build of merging H = 25 +14 %: there such a step takes reward_state)
     constexpr bool pair_items = NO == 2 && S <= 3;
-    __shared__ float item_lds[use_items ? ITEM_FIELDS : 1][use_items ? ITEM_ZERO + 1 : 1];
+    __shared__ float4 item_a[use_items ? ITEM_ZERO + 1 : 1];                 // (x - cx | x, y - cy, wx, wy)
+    __shared__ float2 item_b[use_items ? ITEM_ZERO + 1 : 1];                 // (weight, kind) -> the item's two results
+    __shared__ float2 item_r[use_items && NO == 1 ? ITEM_ZERO + 1 : 1];      // one scripted car: the reciprocals of wx, wy
     if constexpr (use_items) {
-        if (lane == 0) { item_lds[0][ITEM_ZERO] = 0.0f; item_lds[1][ITEM_ZERO] = 0.0f; }
+        if (lane == 0) item_b[ITEM_ZERO] = float2{0.0f, 0.0f};
         __syncthreads();
     }
 
@@ -497,10 +500,7 @@ mpc_chunk_kernel(const KernelParams p)
                             const unsigned long long ms = mc_any & ~multi_c;
                             const bool ac = nc_any && !nc_both && in_lm;
                             const int ic = n_items + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ms >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ms, 0u));
-                            if (ac) {
-                                item_lds[0][ic] = idx; item_lds[1][ic] = idy; item_lds[2][ic] = iwx; item_lds[3][ic] = iwy;
-                                item_lds[4][ic] = w_col; item_lds[5][ic] = 0.0f;
-                            }
+                            if (ac) { item_a[ic] = float4{idx, idy, iwx, iwy}; item_b[ic] = float2{w_col, 0.0f}; }
                             n_items += __popcll(ms);
                             n_items += n_items & 1;
                             const bool ad = nc_both && in_lm;
@@ -508,9 +508,8 @@ mpc_chunk_kernel(const KernelParams p)
                             if (ad) {
 #pragma unroll
                                 for (int j = 0; j < (pair_items ? 2 : 0); ++j) {
-                                    item_lds[0][id + j] = dxl[j]; item_lds[1][id + j] = dyl[j];
-                                    item_lds[2][id + j] = bg[s][j].wx; item_lds[3][id + j] = bg[s][j].wy;
-                                    item_lds[4][id + j] = w_col; item_lds[5][id + j] = 2.0f;
+                                    item_a[id + j] = float4{dxl[j], dyl[j], bg[s][j].wx, bg[s][j].wy};
+                                    item_b[id + j] = float2{w_col, 2.0f};
                                 }
                             }
                             n_items += 2 * __popcll(multi_c);
@@ -521,16 +520,15 @@ mpc_chunk_kernel(const KernelParams p)
                             const int ic = n_items + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mc_any >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mc_any, 0u));
                             slot_c[s] = ac ? ic : ITEM_ZERO;
                             if (ac) {
-                                item_lds[0][ic] = idx; item_lds[1][ic] = idy; item_lds[2][ic] = iwx; item_lds[3][ic] = iwy;
-                                item_lds[4][ic] = w_col; item_lds[5][ic] = 0.0f;
-                                if constexpr (NO == 1) { item_lds[6][ic] = irx; item_lds[7][ic] = iry; }
+                                item_a[ic] = float4{idx, idy, iwx, iwy}; item_b[ic] = float2{w_col, 0.0f};
+                                if constexpr (NO == 1) item_r[ic] = float2{irx, iry};
                             }
                             n_items += __popcll(mc_any);
                         }
                         const bool af = nf && in_lm;
                         const int jf = n_items + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mf >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mf, 0u));
                         slot_f[s] = af ? jf : ITEM_ZERO;
-                        if (af) { item_lds[0][jf] = xn; item_lds[4][jf] = w_f; item_lds[5][jf] = 1.0f; }
+                        if (af) { item_a[jf].x = xn; item_b[jf] = float2{w_f, 1.0f}; }
                         n_items += __popcll(mf);
                         OCD_STAMP(4);
                     }
@@ -539,15 +537,16 @@ mpc_chunk_kernel(const KernelParams p)
                 for (int base = 0; base < n_items; base += 64) {
                     const int i = base + lane;
                     float o1, o2;
-                    const float ia = item_lds[0][i], idy_ = item_lds[1][i], iwx_ = item_lds[2][i], iwy_ = item_lds[3][i];
-                    const float iws = item_lds[4][i], ity = item_lds[5][i];
+                    const float4 ia4 = item_a[i];
+                    const float2 ib2 = item_b[i];
+                    const float ia = ia4.x, idy_ = ia4.y, iwx_ = ia4.z, iwy_ = ia4.w, iws = ib2.x, ity = ib2.y;
                     float irx_ = 1.0f, iry_ = 1.0f;
-                    if constexpr (NO == 1) { irx_ = item_lds[6][i]; iry_ = item_lds[7][i]; }
+                    if constexpr (NO == 1) { const float2 ir2 = item_r[i]; irx_ = ir2.x; iry_ = ir2.y; }
                     if (pair_items && __builtin_expect(any_pair, 0))
                         feature_item_grad<NO, NO == 1>(d, ity == 1.0f, ity == 2.0f, ia, idy_, iwx_, iwy_, irx_, iry_, iws, pkc, o1, o2);
                     else
                         feature_item_grad<NO, NO == 1>(d, ity == 1.0f, false, ia, idy_, iwx_, iwy_, irx_, iry_, iws, pkc, o1, o2);
-                    item_lds[0][i] = o1; item_lds[1][i] = o2;
+                    item_b[i] = float2{o1, o2};
                     OCD_STAMP_COUNT(13);
                 }
                 __syncthreads();
@@ -558,18 +557,16 @@ mpc_chunk_kernel(const KernelParams p)
                     for (int s = 0; s < S; ++s) {
                         const bool pr = (slot_c[s] & ITEM_PAIR_BIT) != 0;
                         const int sc = slot_c[s] & (ITEM_PAIR_BIT - 1), sd2 = pr ? sc + 1 : ITEM_ZERO;
-                        const float c1 = item_lds[0][sc], c2 = item_lds[1][sc], d1 = item_lds[0][sd2], d2 = item_lds[1][sd2];
-                        const float f1 = item_lds[0][slot_f[s]], f2 = item_lds[1][slot_f[s]];
-                        q[s].qx = (((q[s].qx + c1) + d1) + f1) + f2;
-                        q[s].qy = (q[s].qy + c2) + d2;
+                        const float2 rc = item_b[sc], rd = item_b[sd2], rf = item_b[slot_f[s]];
+                        q[s].qx = (((q[s].qx + rc.x) + rd.x) + rf.x) + rf.y;
+                        q[s].qy = (q[s].qy + rc.y) + rd.y;
                     }
                 } else {
 #pragma unroll
                     for (int s = 0; s < S; ++s) {
-                        const float c1 = item_lds[0][slot_c[s]], c2 = item_lds[1][slot_c[s]];
-                        const float f1 = item_lds[0][slot_f[s]], f2 = item_lds[1][slot_f[s]];
-                        q[s].qx = ((q[s].qx + c1) + f1) + f2;
-                        q[s].qy = q[s].qy + c2;
+                        const float2 rc = item_b[slot_c[s]], rf = item_b[slot_f[s]];
+                        q[s].qx = ((q[s].qx + rc.x) + rf.x) + rf.y;
+                        q[s].qy = q[s].qy + rc.y;
                     }
                 }
                 if constexpr (SL < S) {
