@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(64) feature_variants_kernel(const KernelParams
     res[7][0] = res[6][0];
     (void)reward_every<NO, L, true, true>(d, w, x, y, v, sn, cn, bg, q, pkc, &lgc, live_mask);
     res[7][1] = q.qx; res[7][2] = q.qy; res[7][3] = q.qv; res[7][4] = q.qth; ok[7] = guard_f && !degenerate;
-XX
+    // 8: the work-item form (mpc_chunk_kernel's gradient passes; same order in the list: singles, pairs from an even slot, fences)
     res[8][0] = res[0][0];
     ok[8] = false;
     if constexpr (NO <= 2) {
