@@ -13,7 +13,8 @@ mpc_ord.py:128-137): `--config 4 --gpus 8 --scaling strong` / `--config 5 ...` a
 BASELINE.json states them.  `--emulate-rank R/W` runs, on ONE GPU, exactly the block rank R of a W-way strong
 split would run (config 4: 2 048 episodes at H=15, config 5: 4 096 at H=25, for W=8).
 Extra blocks of the same JSON line on rank 0 (single-GPU runs): BASELINE config 2 (pop 16 x 8 inits, 128
-episodes: the small-batch latency case), the rank-0-of-8 shares of configs 4 and 5, and the REFERENCE's own shape
+episodes: the small-batch latency case), the rank-0-of-8 shares of configs 4 and 5 and the two configs whole on this one
+GPU (`config4_whole`, `config5_whole`: 16 384 / 32 768 episodes per launch), and the REFERENCE's own shape
 (`reference_h5`: finite_horizon H=5, pycma's default population 9 x 3 inits, K=3 -- what a user of
 `run_mpc_ord.py finite_horizon cmaes --n_inits 3` gets per generation; `reference_h6_extra`: H=6, n_iter 200,
 extra_inits K=6, the validation scripts' planner), each with its own CMA-ES generation wall-clock and a bounded CPU
@@ -487,7 +488,10 @@ def main():
         dt_, k_, fit_, ctx_ = timed_generations(cfg_index, P, w, r, steps, warmup, collective=False)
         b = block(cfg_index, dt_, k_, ctx_, steps, per_gpu_only=True)
         b["parity"] = parity_of(ctx_)
-        b["emulated_rank"] = f"{r}/{w}"
+        if w > 1:
+            b["emulated_rank"] = f"{r}/{w}"
+        else:
+            b["sharding"] = "the whole population on this one GPU (no split, no collective)"
         b["generation_cost_checksum"] = float(np.sum(fit_))
         if not args.no_cpu_baseline:                                # this rank's candidate block on the host's cores
             lo_, hi_ = sharding.candidate_block(P, w, r)
@@ -776,6 +780,9 @@ def main():
             # what ONE of 8 GPUs runs of BASELINE configs 4 / 5 (strong split): the shapes the 8-GPU lines are made of
             n_sh = max(3, min(args.steps, 20))
             shares = {f"config{c}_share8": share_block(c, 0, 8, n_sh, 2) for c in (4, 5)}
+            # ... and the two configs WHOLE on this one GPU (16 384 / 32 768 episodes per launch: three / eight wavefronts per
+            # SIMD, the shared-SIMD builds of the chunked kernel with their work-item lists)
+            shares.update({f"config{c}_whole": share_block(c, 0, 1, 3, 1) for c in (4, 5)})
         if world > 1 and not emulate:
             # BASELINE configs 4 / 5 as BASELINE.json states them: the fixed population split over the ranks (strong
             # scaling; mpc_ord.py:128-137, run_mpc_ord.py:83-90), the all-gather of the returns inside every timed step

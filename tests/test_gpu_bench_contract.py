@@ -21,7 +21,7 @@ def test_bench_json_line():
     d = json.loads(r.stdout)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "cma_generation_ms", "config2",
-              "config4_share8", "config5_share8", "reference_h5", "reference_h6_extra", "reference_h5_x28", "config1", "collective"):
+              "config4_share8", "config5_share8", "config4_whole", "config5_whole", "reference_h5", "reference_h6_extra", "reference_h5_x28", "config1", "collective"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["dtype"] == "f32" and d["data"] == "synthetic"
     assert d["vs_baseline"] is None and d["higher_is_better"] is True and d["scaling"] == "weak"
@@ -52,6 +52,14 @@ def test_bench_json_line():
     for sb in (s4, s5):
         assert abs(sb["value"] - sb["episodes_per_gpu"] / (sb["ms_per_step"] * 1e-3)) / sb["value"] < 1e-6
         assert sb["roofline"]["kernel_ms"] <= sb["ms_per_step"] * 1.04      # (six timed steps: one slow launch moves their mean)
+    # ... and the two configs whole on this one GPU (the shared-SIMD builds of the chunked kernel), parity attached
+    w4, w5 = d["config4_whole"], d["config5_whole"]
+    assert w4["episodes_per_gpu"] == 16384 and w5["episodes_per_gpu"] == 32768 and "emulated_rank" not in w4
+    for wb in (w4, w5):
+        assert wb["parity"]["episodes_checked"] >= 256 and wb["parity"]["bitwise_equal"] == wb["parity"]["episodes_checked"]
+        assert abs(wb["value"] - wb["episodes_per_gpu"] / (wb["ms_per_step"] * 1e-3)) / wb["value"] < 1e-6
+        assert wb["roofline"]["kernel_ms"] <= wb["ms_per_step"] * 1.04 and wb["roofline"]["launch"]["mapping"] == "chunked"
+    assert w4["ms_per_step"] < 17.0 and w5["ms_per_step"] < 35.0        # (measured 14.1 / 30.3 ms; before the work items 18.3 / 37.7)
     sp = d["cma"]["host_split_ms"]
     assert set(sp) >= {"ask", "normalise", "launch", "kernel_gather_readback", "reduce", "tell"}
     # the launch kernel_ms times writes where the timed step's launch writes
