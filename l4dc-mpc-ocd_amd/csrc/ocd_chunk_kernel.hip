@@ -449,9 +449,10 @@ mpc_chunk_kernel(const KernelParams p)
                 // Active features as work items (ocd_device.h: reward_base_grad / feature_item_grad): every (lane, step) pair
                 // gets the features every state has; its active fence / collision terms go to a list in LDS, are evaluated
                 // 64 at a time and come back as two adjoint terms each.  A state inside BOTH cars' boxes appends its two
-                // collision items side by side at an even slot (the evaluation compares the two lanes' products).  A step
-                // beyond the guards of the shortened divisions, with a degenerate car width, under the diagnostics knobs or
-                // beyond the list's capacity evaluates every feature of every lane (reward_state), as before.
+                // collision items side by side at an even slot (the evaluation compares the two lanes' products; pair_items
+                // builds -- in the others such a step goes the way of the next sentence).  A step beyond the guards of the
+                // shortened divisions, with a degenerate car width, under the diagnostics knobs or beyond the list's capacity
+                // evaluates every feature of every lane (reward_state), as before.
                 float x = xs, y = ys;
                 int n_items = 0;                               // wave-uniform
                 bool any_pair = false;                         // wave-uniform: some state of this pass is inside both boxes
