@@ -439,12 +439,12 @@ class MPC_ORD:
                 t_chunk = time.perf_counter()
                 done, why, pending = es.run(a, overrides)
                 book(0, done)
-                for g in range(done):
-                    self.generation_seconds.append(float(secs[g, 0]))
-                    self.fitness_seconds.append(float(secs[g, 2:7].sum()))
-                    self.n_nonfinite.append(int(nonf[g]))
+                if done:                                           # (whole columns at a time: no interpreter work per generation)
+                    self.generation_seconds.extend(secs[:done, 0].tolist())
+                    self.fitness_seconds.extend(secs[:done, 2:7].sum(axis=1).tolist())
+                    self.n_nonfinite.extend(nonf[:done].tolist())
                     for k, name in enumerate(names):
-                        self.host_split.setdefault(name, []).append(float(secs[g, 1 + k]))
+                        self.host_split.setdefault(name, []).extend(secs[:done, 1 + k].tolist())
                 if done:        # what the C timers do not see: this call's share of the interpreter (history, counters)
                     self.generation_wall_seconds.extend([(time.perf_counter() - t_chunk) / done] * done)
                 if pending:                                        # generation `done` is evaluated, not told: redraw its NaN
