@@ -31,7 +31,8 @@ def main():
     ap.add_argument("--json", action="store_true", help="one JSON line with the placement summary instead of the tables (tests/test_gpu_placement.py)")
     ap.add_argument("--warm", type=int, default=0, help="untimed launches before the stamped one")
     a = ap.parse_args()
-    os.environ["OCD_HIP_LIB"] = os.path.join(ROOT, "l4dc-mpc-ocd_amd", "csrc", "libocd_hip_stamps_light.so" if a.light else "libocd_hip_stamps.so")
+    os.environ["OCD_HIP_LIB"] = os.environ.get("OCD_STAMPS_LIB") or os.path.join(      # (OCD_STAMPS_LIB: an experimental stamps build)
+        ROOT, "l4dc-mpc-ocd_amd", "csrc", "libocd_hip_stamps_light.so" if a.light else "libocd_hip_stamps.so")
     import torch
     from l4dc_mpc_ocd_amd import scenarios
     from l4dc_mpc_ocd_amd.engine import Engine
