@@ -151,6 +151,7 @@ def cpu_baseline(scn, inits, w32, budget_s=16.0):
         orc.rollout(scn.desc, inits, w32, ep_begin=0, ep_end=n, n_threads=cores)
     dt = time.perf_counter() - t0
     return {"value": reps * n / dt, "unit": "episodes/s", "cores": cores, "kind": "port",
+            "sample_short": f"{reps} x first {n} of {E} episodes, {cores} OpenMP threads, {dt:.1f} s",
             "sample": f"{reps} x the first {n} of the {E} episodes of the workload, OpenMP over episodes on {cores} "
                       f"threads, {dt:.1f} s of CPU work (oracle/ocd_oracle.c)"}
 
@@ -208,6 +209,130 @@ def parity_sample(scn, eng, inits, w32, e0, e1, n_want, n_threads):
 
 PARITY_KEYS = ("episodes_checked", "bitwise_equal", "within_1e-4_rel", "plan_steps_checked", "argmin_flips",
                "nonfinite_returns")
+
+
+# ---- the printed line and its side file ---------------------------------------------------------------------------
+# stdout carries ONE line of at most LINE_CAP bytes: the contract's keys, a compact `roofline`, `cpu_baseline`, `parity`,
+# `collective`, and per extra block six numbers.  Everything else (launch records, host splits, rocprof replay objects,
+# the sentences that say what was sampled and against what) is written whole to DETAIL_NAME beside this file (or to
+# $OCD_BENCH_DETAIL); the line names that file.  Round 5's line had grown to 32 KB and the driver could not parse it.
+LINE_CAP = 8192
+DETAIL_NAME = "bench_detail.json"
+
+
+def _sig(x, digits=7):
+    """Floats of the extra blocks to 7 significant digits (the contract's own keys are printed in full)."""
+    if isinstance(x, float) and np.isfinite(x):
+        return float(f"{x:.{digits}g}")
+    return x
+
+
+def parity_ok(par):
+    """One flag of a `parity` object: something was checked, every checked episode is bit for bit the oracle's (returns,
+    world states, applied controls), every return is within 1e-4 relative and no kept control initialisation differs."""
+    if not par:
+        return None
+    if "episodes_checked" in par and "bitwise_equal" in par:
+        n = par["episodes_checked"]
+        return bool(n > 0 and par["bitwise_equal"] == n and par.get("within_1e-4_rel", n) == n
+                    and par.get("argmin_flips", 0) == 0)
+    flags = [v for k, v in par.items() if k.endswith("bitwise_equal")]
+    return bool(flags and all(flags))
+
+
+def compact_parity(par):
+    if not par:
+        return None
+    return {k: par[k] for k in ("episodes_checked", "bitwise_equal", "within_1e-4_rel", "argmin_flips") if k in par}
+
+
+def compact_roofline(rf):
+    keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "binding", "binding_frac",
+            "binding_achieved", "binding_peak", "binding_unit")
+    out = {k: rf[k] for k in keep if k in rf}
+    out["kernel"] = rf.get("kernel_symbol") or rf.get("kernel")
+    rp = rf.get("rocprof") or {}
+    if rp.get("replayed"):                                   # the committed rocprofv3 summary this kernel_ms must agree with
+        out["rocprof_avg_ms"] = rp.get("kernel_steady_avg_ms")
+        out["rocprof_file"] = rp.get("profile")
+    return out
+
+
+def compact_block(b):
+    """The six numbers of an extra block (+ its CMA-ES generation wall-clock and CPU figure where it has them)."""
+    rf = b.get("roofline") or {}
+    out = {"episodes": b.get("episodes_per_gpu", b.get("episodes", b.get("episodes_per_generation"))),
+           "ms_per_step": b.get("ms_per_step"), "value": b.get("value"),
+           "kernel_ms": rf.get("kernel_ms", b.get("kernel_ms")), "binding_frac": rf.get("binding_frac"),
+           "parity_ok": parity_ok(b.get("parity"))}
+    for k in ("cma_generation_ms", "eval_weights_ms", "world_step_ms", "runs", "generation_ms_ratio_to_one_run"):
+        if k in b:
+            out[k] = b[k]
+    if b.get("cpu_baseline"):
+        out["cpu_value"] = b["cpu_baseline"]["value"]
+    return {k: _sig(v) for k, v in out.items() if v is not None or k == "parity_ok"}
+
+
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data")
+
+
+def compact_line(out, detail_path):
+    """The printed line from the full record `out`."""
+    line = {k: out[k] for k in CONTRACT_KEYS}
+    cfg = out["config"]
+    line["config"] = {"workload": cfg["workload"], "episodes_per_generation": cfg["episodes_per_generation"],
+                      "episodes_per_gpu": cfg["episodes_per_gpu"], "sharding": cfg["sharding"]}
+    line["roofline"] = compact_roofline(out["roofline"])
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                "sample": cb.get("sample_short") or cb.get("sample", "")[:120]}
+    if out.get("parity"):
+        line["parity"] = compact_parity(out["parity"])
+    co = out.get("collective")
+    if co:
+        line["collective"] = ({"error": co["error"][:120]} if "error" in co else
+                              {"backend": co["backend"], "ranks_seen": co["ranks_seen"],
+                               "all_gather_us": _sig(co["all_gather_us"]), "in_timed_step": co.get("in_timed_step")})
+    if "cma_generation_ms" in out:
+        line["cma_generation_ms"] = out["cma_generation_ms"]
+    for k, v in out.items():
+        if isinstance(v, dict) and k not in line and k not in ("valu", "cma", "profiled", "predicted_strong_scaling") \
+                and ("ms_per_step" in v or "kernel_ms" in v):
+            line[k] = compact_block(v)
+    pss = out.get("predicted_strong_scaling")
+    if pss:                                                   # per config: [N, predicted ms, speed-up, efficiency] rows
+        line["predicted_strong_scaling"] = {
+            "measured_on": "every rank's block timed on ONE GPU + the one-rank all-gather; NOT an N-GPU run",
+            **{c: [[r["n_gpus"], _sig(r["generation_ms"], 4), _sig(r["speedup"], 3), _sig(r["efficiency"], 3)]
+                   for r in t["rows"]] for c, t in pss["configs"].items()}}
+    line["detail"] = detail_path
+    return line
+
+
+def write_detail(out):
+    """The full record, whole, beside bench.py (or at $OCD_BENCH_DETAIL); returns the path the line names (None if
+    nowhere was writable: the line is still printed)."""
+    want = os.environ.get("OCD_BENCH_DETAIL") or os.path.join(ROOT, DETAIL_NAME)
+    for path in (want, os.path.join(os.environ.get("TMPDIR", "/tmp"), DETAIL_NAME)):
+        try:
+            tmp = f"{path}.tmp.{os.getpid()}"
+            with open(tmp, "w") as f:
+                json.dump(out, f, indent=1)
+            os.replace(tmp, path)
+            return os.path.relpath(path, ROOT) if path.startswith(ROOT + os.sep) else path
+        except OSError:
+            continue
+    return None
+
+
+def print_line(out, line_out):
+    line = compact_line(out, write_detail(out))
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) >= LINE_CAP:
+        raise SystemExit(f"bench.py: the line is {len(text)} bytes (cap {LINE_CAP}); move keys to {DETAIL_NAME}")
+    print(text, file=line_out, flush=True)
 
 
 def spawn_ranks(args):
@@ -482,10 +607,14 @@ def main():
         out["seconds"] = time.perf_counter() - t0
         return out
 
-    def share_block(cfg_index, r, w, steps, warmup):
-        """Rank r's block of a w-way strong split of BASELINE config cfg_index, on this GPU alone."""
+    def share_block(cfg_index, r, w, steps, warmup, light=False):
+        """Rank r's block of a w-way strong split of BASELINE config cfg_index, on this GPU alone (light: the timing
+        only, no parity sample and no CPU figure -- the rows of `predicted_strong_scaling`)."""
         P = scenarios.BASELINE_CONFIGS[cfg_index]["pop"]
         dt_, k_, fit_, ctx_ = timed_generations(cfg_index, P, w, r, steps, warmup, collective=False)
+        if light:
+            return {"emulated_rank": f"{r}/{w}", "episodes_per_gpu": ctx_[7], "ms_per_step": dt_ / steps * 1e3,
+                    "kernel_ms": k_, "generation_cost_checksum": float(np.sum(fit_))}
         b = block(cfg_index, dt_, k_, ctx_, steps, per_gpu_only=True)
         b["parity"] = parity_of(ctx_)
         if w > 1:
@@ -598,6 +727,18 @@ def main():
                "value": E / (float(np.median(wall)) * 1e-3), "unit": "episodes/s",
                "stop_reason": sorted({k for o in res.runs for k in o.stop_reason}),
                "sampler_parity": "unpinned (own CMA-ES, pycma absent); every run's history is bit for bit the run alone (tests/test_gpu_lockstep.py)"}
+        if not args.no_parity:                                      # the indexed launch's returns against the oracle, run by run
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib
+            orc = oracle_lib.load()
+            got = ret.cpu().numpy()
+            want = np.concatenate([orc.rollout(scn.desc, runs[r][0], w_all[r * pop:(r + 1) * pop],
+                                               n_threads=usable_cores())["returns"].reshape(-1) for r in range(R)])
+            with np.errstate(invalid="ignore"):
+                close = np.abs(got.astype(np.float64) - want) <= 1e-4 * np.maximum(1e-2, np.abs(want))
+            out["parity"] = {"episodes_checked": int(got.size), "bitwise_equal": int(_same_bits(got, want).sum()),
+                             "within_1e-4_rel": int(close.sum()),
+                             "against": "oracle/ocd_oracle.c, untimed: the returns of one indexed launch over all runs"}
         if not args.no_cpu_baseline:                                # the same R populations on the host's cores
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib
@@ -614,6 +755,29 @@ def main():
                                    "sample": f"{reps} x the {R} populations ({E} episodes), one oracle call per run with OpenMP over its "
                                              f"episodes on {cores} threads, {dt_c:.1f} s of CPU work (oracle/ocd_oracle.c)"}
         return out
+
+    def predicted_strong_scaling(whole, gather_us, steps=3):
+        """What the ONE-GPU measurements predict for BASELINE configs 4 / 5 split over N = 1, 2, 4, 8 GPUs (strong scaling:
+        run_mpc_ord.py:83-90, mpc_ord.py:128-137 split a fixed batch): for every N, EVERY rank's candidate block run on
+        this GPU alone (the step as a rank runs it: launch, wait, float64 reduction); the generation takes the slowest
+        block + the all-gather of the returns (measured here on a one-rank RCCL group: the N-rank gather is not
+        measured).  Unmeasured on N GPUs -- a prediction, flagged as one."""
+        table = {}
+        for c in (4, 5):
+            rows = []
+            base = whole[c]["ms_per_step"]
+            for n in (1, 2, 4, 8):
+                if n == 1:
+                    per_rank = [base]
+                else:
+                    per_rank = [share_block(c, r, n, steps, 1, light=True)["ms_per_step"] for r in range(n)]
+                gen = max(per_rank) + (gather_us * 1e-3 if n > 1 else 0.0)
+                rows.append({"n_gpus": n, "generation_ms": gen, "slowest_block_ms": max(per_rank),
+                             "fastest_block_ms": min(per_rank), "block_ms_per_rank": per_rank,
+                             "speedup": base / gen, "efficiency": base / gen / n})
+            table[f"config{c}"] = {"episodes_per_generation": whole[c]["episodes_per_generation"], "rows": rows}
+        return {"status": "PREDICTED from one-GPU runs of every rank's block; unmeasured on N GPUs",
+                "all_gather_us_assumed": gather_us, "configs": table}
 
     def config1_block(reps=40):
         """BASELINE config 1 -- finite_horizon, 3 inits, the designer's ("true") weights, H = 5: the README's `vis` path
@@ -816,6 +980,7 @@ def main():
                     continue
                 dt_r, k_r, fit_r, ctx_r = timed_generations(name, spec["pop"], 1, 0, n_rf, 2, collective=False)
                 b = block(name, dt_r, k_r, ctx_r, n_rf)
+                b["parity"] = parity_of(ctx_r)
                 b["generation_cost_checksum"] = float(np.sum(fit_r))
                 c = cma_generations(spec, None, reduce_over_ranks=False)      # popsize None: pycma's default 9
                 b["cma_generation_ms"], b["cma"] = c["cma_generation_ms"], c
@@ -887,7 +1052,10 @@ def main():
         coll["in_timed_step"] = True
     if rank == 0:
         out["collective"] = coll
-        print(json.dumps(out), file=line_out, flush=True)
+        if world == 1 and "config4_whole" in shares and "config5_whole" in shares:
+            g_us = coll["all_gather_us"] if coll and "all_gather_us" in coll else 0.0
+            out["predicted_strong_scaling"] = predicted_strong_scaling({4: shares["config4_whole"], 5: shares["config5_whole"]}, g_us)
+        print_line(out, line_out)
     if dist.is_initialized():
         dist.destroy_process_group()
 
