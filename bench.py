@@ -297,6 +297,8 @@ def compact_line(out, detail_path):
                                "all_gather_us": _sig(co["all_gather_us"]), "in_timed_step": co.get("in_timed_step")})
     if "cma_generation_ms" in out:
         line["cma_generation_ms"] = out["cma_generation_ms"]
+    if "generation_cost_checksum" in out:
+        line["generation_cost_checksum"] = out["generation_cost_checksum"]
     for k, v in out.items():
         if isinstance(v, dict) and k not in line and k not in ("valu", "cma", "profiled", "predicted_strong_scaling") \
                 and ("ms_per_step" in v or "kernel_ms" in v):
@@ -654,8 +656,9 @@ def main():
             med = float(tt.item())
         return {"cma_generation_ms": med, "cma_generation_native_timers_ms": float(np.median(gs_native)),
                 "fitness_ms": float(np.median(fs)),
-                "sampler_parity": "unpinned: own CMA-ES (pycma is not installed; sampler and termination table restated "
-                                  "from its documentation), the fitness values it is fed are bit-exact",
+                "sampler_parity": "random stream unpinned (own CMA-ES, pycma is not installed); strategy parameters and the "
+                                  "active update pinned to arXiv 1604.00772 Table 1 / eqs. 46-58 "
+                                  "(tests/test_cma_paper_constants.py); the fitness values it is fed are bit-exact",
                 "generations_run": int(len(m.generation_seconds)), "generations_timed": int(len(gs)),
                 "popsize": int(m.es.lam), "n_inits": cfg["n_inits"], "stop_reason": {k: (None if v is None else float(v)) for k, v in m.stop_reason.items()},
                 "n_nonfinite": int(sum(m.n_nonfinite)), "n_resampled": int(m.n_resampled),

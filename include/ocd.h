@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define OCD_ABI_VERSION 2
+#define OCD_ABI_VERSION 3   /* 3: lane_origin_y / lane_normal_y (the y-term of StraightLane.dist2median in the scored reward);
+                              * ocd_rollout_indexed, ocd_debug_feature_variants; out-of-range index rows are an error */
 
 #define OCD_MAX_CARS 4      /* ego + up to 3 scripted cars                    */
 #define OCD_MAX_OTHERS 3
@@ -130,6 +131,17 @@ typedef struct ocd_scenario_desc {
      * set (planner_car.py:66-75): default_control if the car has a plan and a default_control, else
      * (0, 0) -- also for a FixedControlCar, whose REAL control is other_default. */
     float other_assumed_default[OCD_MAX_OTHERS][2];
+
+    /* ---- ABI 3 ---- */
+    /* StraightLane.dist2median is r = (x - p[0]) * n[0] + (y - p[1]) * n[1] with the lane normal n = (-1, 0.0)
+     * (world.py:184-187,216-217): the second term is +-0 for every finite y and NaN for y = +-inf / NaN.  The SCORED
+     * reward -- car.reward_fn(past_state, ...) of mpc_ord.py:99, ocd_reward_batch -- carries it, so an episode whose
+     * ego leaves the finite numbers scores NaN exactly as the reference's does; the planner's objective and its
+     * gradient (naive_planner.py:33-77) keep r = (x - p[0]) * -1 (identical bits for every finite y).
+     * lane_origin_y = StraightLane.p[1] (-5 in both worlds, world.py:150,157); lane_normal_y = n[1] must be 0:
+     * lanes run along y, anything else is OCD_ERR_UNSUPPORTED. */
+    float lane_origin_y;
+    float lane_normal_y;
 } ocd_scenario_desc;
 
 typedef struct ocd_scenario ocd_scenario; /* opaque: validated descriptor + device-side constants */
@@ -279,7 +291,11 @@ int32_t ocd_rollout_episodes(const ocd_scenario *scn,
  *                 call that starts it in ITS OWN sequential evaluation (= its flat index (p*N + n)*S + s inside its run,
  *                 plus that run's reset_phase): selects the entry of the teleport cycle exactly as ocd_rollout_episodes
  *                 does for episode e (reset % teleport_period, or reset % n_samples when the period is 0).
- *                 Device-addressable memory (device or pinned host); rows outside [0, P_rows) / [0, N_rows) are clamped.
+ *                 Device-addressable memory (device, or pinned / registered host).  A row outside [0, P_rows) / [0, N_rows)
+ *                 or with a negative reset number is an ERROR, not clamped (ABI 3): an index in host memory is checked
+ *                 before anything is launched -> OCD_ERR_INVALID_ARG naming the row; an index in device memory is checked by
+ *                 the kernel -- that episode's return is NaN, and ocd_scenario_index_error (after the stream has been
+ *                 waited for) or the next ocd_rollout_indexed on the handle returns OCD_ERR_INVALID_ARG naming the row.
  *   returns_out   [E]; traj_out [E, T+1, C, 4] or NULL; ctrl_out [E, T, 2] or NULL -- in index order.
  * Episode i is bit for bit the episode ocd_rollout_episodes computes for the same (candidate, init, reset).
  */
@@ -289,6 +305,11 @@ int32_t ocd_rollout_indexed(const ocd_scenario *scn,
                             const int32_t *episode_index, int64_t E,
                             float *returns_out, float *traj_out, float *ctrl_out,
                             void *hip_stream);
+
+/* Device-memory indices of ocd_rollout_indexed: OCD_OK if no completed launch on this handle has met an out-of-range index
+ * row since the last call, else OCD_ERR_INVALID_ARG with *bad_row (may be NULL) = the position of such a row in its index
+ * (the error is cleared by reporting it).  Call it after the launch's stream has been waited for. */
+int32_t ocd_scenario_index_error(const ocd_scenario *scn, int64_t *bad_row);
 
 /*
  * The same episode loop started from arbitrary world states instead of

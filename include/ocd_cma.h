@@ -23,17 +23,25 @@ extern "C" {
 #endif
 
 #define OCD_CMA_MAX_DIM 64
-#define OCD_CMA_ABI_VERSION 5      /* 2: tell returns the non-finite count; resample, stop_state, abi_version; 3: normalise_weights; 4: stop, run; 5: 12 stop rules (noeffectaxis, noeffectcoord), add_evals, run_many */
+#define OCD_CMA_ABI_VERSION 6      /* 6: the tutorial's weights ln((lambda+1)/2) - ln i over all ranks, active update on by default, set_active, weights; 2: tell returns the non-finite count; resample, stop_state, abi_version; 3: normalise_weights; 4: stop, run; 5: 12 stop rules (noeffectaxis, noeffectcoord), add_evals, run_many */
 #define OCD_CMA_N_STOP 12          /* termination rules of ocd_cma_stop */
 
 typedef struct ocd_cma ocd_cma;
 
-/* (mu/mu_w, lambda)-CMA-ES with Hansen's default strategy parameters, started at x0 [n] with step size sigma0;
+/* (mu/mu_w, lambda)-CMA-ES with the default strategy parameters of Hansen's tutorial (arXiv 1604.00772, Table 1:
+ * weights ln((lambda+1)/2) - ln i, negative weights in the rank-mu update = pycma's CMA_active default), started at x0
+ * [n] with step size sigma0;
  * popsize 0 = 4 + floor(3 ln n) (pycma's default: 9 for the 7 weights of ThreeLaneTestCar); the normal deviates are
  * numpy.random.RandomState(seed).standard_normal's stream, bit for bit. */
 int32_t ocd_cma_create(int32_t n, const double *x0, double sigma0, int32_t popsize, uint32_t seed, ocd_cma **out);
 void ocd_cma_destroy(ocd_cma *es);
 int32_t ocd_cma_popsize(const ocd_cma *es);
+/* The active update (negative recombination weights, tutorial eqs. 46-47, 50-53) on / off; on after create (pycma's
+ * default).  Only before the first tell: -1 afterwards. */
+int32_t ocd_cma_set_active(ocd_cma *es, int32_t on);
+/* w [lambda] <- the recombination weights (positive first); consts [8] <- mueff, cc, csigma, c1, cmu, dsigma, chiN,
+ * the sum of all weights.  Either may be NULL. */
+int32_t ocd_cma_weights(const ocd_cma *es, double *w, double *consts);
 /* OCD_CMA_ABI_VERSION of the built library: the binding refuses a stale libocd_cma.so. */
 int32_t ocd_cma_abi_version(void);
 

@@ -11,7 +11,7 @@ import ctypes as C
 import os
 from typing import Optional
 
-OCD_ABI_VERSION = 2
+OCD_ABI_VERSION = 3
 OCD_MAX_CARS = 4
 OCD_MAX_OTHERS = 3
 OCD_MAX_LANES = 4
@@ -68,6 +68,8 @@ class ScenarioDesc(C.Structure):
         ("designer_weights", C.c_float * OCD_MAX_FEATURES),
         ("teleport_period", C.c_int32),
         ("other_assumed_default", (C.c_float * 2) * OCD_MAX_OTHERS),
+        ("lane_origin_y", C.c_float),
+        ("lane_normal_y", C.c_float),
     ]
 
     @property
@@ -103,6 +105,7 @@ HIP_SYMBOLS = [
      [_VP, _VP, _VP, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _VP, _VP, _VP, _VP]),
     ("ocd_rollout_indexed", C.c_int32,
      [_VP, _VP, C.c_int64, _VP, C.c_int64, _VP, C.c_int64, _VP, _VP, _VP, _VP]),
+    ("ocd_scenario_index_error", C.c_int32, [_VP, C.POINTER(C.c_int64)]),
     ("ocd_rollout_from_state", C.c_int32,
      [_VP, _VP, _VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _VP, _VP, _VP, C.c_int64, _VP]),
     ("ocd_mpc_reward_batch", C.c_int32,

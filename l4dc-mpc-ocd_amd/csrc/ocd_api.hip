@@ -38,6 +38,9 @@ struct ocd_scenario {
     int32_t n_cus[OCD_MAX_DEVICES];
     int32_t two_sided = 0;                 // fence_shape * fence_width < 1/80: generic kernels, both fence sides (ocd_kernels.h)
     mutable int32_t last_launch[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ocd_scenario_last_launch (guarded by mu)
+    // ocd_rollout_indexed with a DEVICE-memory index: the kernels report an out-of-range row here (pinned host memory the
+    // device writes; 1 + the row's position); sticky until ocd_scenario_index_error reads it
+    mutable int32_t *index_error = nullptr;
 };
 
 #ifdef OCD_STAMPS
@@ -76,6 +79,9 @@ int32_t validate(const ocd_scenario_desc *d)
     if (d->n_lanes < 0 || d->n_lanes > OCD_MAX_LANES) return fail(OCD_ERR_INVALID_ARG, "n_lanes %d out of [0,%d]", d->n_lanes, OCD_MAX_LANES);
     if (d->reward_kind == OCD_REWARD_LANE_FEATURES && (d->n_lanes < 1 || d->n_cars < 2))
         return fail(OCD_ERR_INVALID_ARG, "lane-feature reward needs >=1 lane and >=1 scripted car");
+    if (d->reward_kind == OCD_REWARD_LANE_FEATURES && !(d->lane_normal_y == 0.0f))
+        return fail(OCD_ERR_UNSUPPORTED, "lane_normal_y = %g: lanes run along y (StraightLane.n = (-1, 0), world.py:150-158); "
+                                         "the planner's lane offset has no y-term", (double)d->lane_normal_y);
     if (d->horizon < 1 || d->horizon > OCD_MAX_HORIZON) return fail(OCD_ERR_INVALID_ARG, "horizon %d out of [1,%d]", d->horizon, OCD_MAX_HORIZON);
     if (d->n_iter < 0) return fail(OCD_ERR_INVALID_ARG, "n_iter %d < 0", d->n_iter);
     if (d->episode_len < 0) return fail(OCD_ERR_INVALID_ARG, "episode_len %d < 0", d->episode_len);
@@ -338,6 +344,7 @@ void ocd_scenario_destroy(ocd_scenario *scn)
         if (scn->dev_plans[i]) (void)hipFree(scn->dev_plans[i]);
     for (int i = 0; i < OCD_MAX_DEVICES; ++i)
         if (scn->dev_leaf[i]) (void)hipFree(scn->dev_leaf[i]);
+    if (scn->index_error) (void)hipHostFree(scn->index_error);
     delete scn;
 }
 
@@ -473,6 +480,8 @@ int32_t ocd_rollout_indexed(const ocd_scenario *scn, const float *init_states, i
     if (E < 0) return fail(OCD_ERR_INVALID_ARG, "E = %lld < 0", (long long)E);
     if (E == 0) return OCD_OK;
     if (!episode_index) return fail(OCD_ERR_INVALID_ARG, "episode_index is NULL");
+    if (P_rows > INT32_MAX || N_rows > INT32_MAX)
+        return fail(OCD_ERR_INVALID_ARG, "P_rows / N_rows beyond what an int32 index row can name");
     ocd::KernelParams p;
     // (the flat-range checks of rollout_params on a population of P_rows x N_rows; the launch then covers E index rows)
     int32_t st = rollout_params(scn, init_states, cand_weights, P_rows, N_rows, 0, 0, returns_out, traj_out, ctrl_out, nullptr, p);
@@ -482,9 +491,54 @@ int32_t ocd_rollout_indexed(const ocd_scenario *scn, const float *init_states, i
     p.P_rows = P_rows;
     st = need_device();
     if (st != OCD_OK) return st;
+    // An index row outside the tables is a caller bug, never a clamp (round 5 clamped: a wrong-but-plausible fitness).
+    // Host memory (pinned / registered: what the native lockstep loop builds its index in) is checked here, before anything
+    // is launched; device memory is checked by the kernels, which report through the handle's pinned error word.
+    hipPointerAttribute_t attr;
+    const hipError_t pe = hipPointerGetAttributes(&attr, episode_index);
+    if (pe != hipSuccess) (void)hipGetLastError();               // (plain host memory: not device-addressable, caught below)
+    const bool host_index = pe == hipSuccess && attr.type == hipMemoryTypeHost;
+    if (pe != hipSuccess || attr.type == hipMemoryTypeUnregistered)
+        return fail(OCD_ERR_INVALID_ARG, "episode_index is not device-addressable memory (device, or pinned / registered host)");
+    if (host_index) {
+        for (int64_t e = 0; e < E; ++e) {
+            const int32_t *ix = episode_index + 3 * e;
+            if (ix[0] < 0 || ix[0] >= P_rows || ix[1] < 0 || ix[1] >= N_rows || ix[2] < 0)
+                return fail(OCD_ERR_INVALID_ARG, "episode_index row %lld = (%d, %d, %d): candidate row outside [0, %lld), init row "
+                            "outside [0, %lld) or negative reset number", (long long)e, ix[0], ix[1], ix[2], (long long)P_rows, (long long)N_rows);
+        }
+    } else {
+        std::lock_guard<std::mutex> lock(const_cast<ocd_scenario *>(scn)->mu);
+        if (!scn->index_error) {
+            int32_t *w = nullptr;
+            const hipError_t he = hipHostMalloc((void **)&w, 2 * sizeof(int32_t), hipHostMallocMapped);
+            if (he != hipSuccess) return hip_fail(he, "hipHostMalloc(index error word)");
+            w[0] = 0; w[1] = 0;
+            scn->index_error = w;
+        }
+        if (scn->index_error[0] != 0) {
+            const int32_t row = scn->index_error[0] - 1;
+            scn->index_error[0] = 0;
+            return fail(OCD_ERR_INVALID_ARG, "an earlier ocd_rollout_indexed launch on this handle found episode_index row %d out of "
+                                             "range (its return is NaN); nothing was launched now", row);
+        }
+        p.index_error = scn->index_error;
+    }
     st = scripted_plans_device(scn, (hipStream_t)hip_stream, &p.other_plans);
     if (st != OCD_OK) return st;
     return launch(scn, p, hip_stream);
+}
+
+int32_t ocd_scenario_index_error(const ocd_scenario *scn, int64_t *bad_row)
+{
+    if (!scn) return fail(OCD_ERR_INVALID_ARG, "scenario is NULL");
+    std::lock_guard<std::mutex> lock(const_cast<ocd_scenario *>(scn)->mu);
+    if (bad_row) *bad_row = -1;
+    if (!scn->index_error || scn->index_error[0] == 0) return OCD_OK;
+    const int32_t row = scn->index_error[0] - 1;
+    scn->index_error[0] = 0;
+    if (bad_row) *bad_row = row;
+    return fail(OCD_ERR_INVALID_ARG, "ocd_rollout_indexed: episode_index row %d was out of range (that episode's return is NaN)", row);
 }
 
 int32_t ocd_rollout_from_state(const ocd_scenario *scn, const float *world_state,

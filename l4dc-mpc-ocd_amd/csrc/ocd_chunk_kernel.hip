@@ -124,9 +124,9 @@ mpc_chunk_kernel(const KernelParams p)
     int tp_idx = 0;
     if (p.mode == OCD_MODE_ROLLOUT && !p.from_state) {
         long long p_, n_;
-        episode_rows(p, prob, p_, n_, tp_idx);
+        const bool row_ok = episode_rows(p, prob, p_, n_, tp_idx);
         const float *ini = p.ego_states + 4 * n_;
-        ex = ini[0]; ey = ini[1]; ev = ini[2]; eth = ini[3];
+        ex = row_ok ? ini[0] : __builtin_nanf(""); ey = ini[1]; ev = ini[2]; eth = ini[3];
 #pragma unroll
         for (int j = 0; j < NO; ++j) {
             ox[j] = d.other_init[j][0]; oy[j] = d.other_init[j][1];
@@ -197,7 +197,7 @@ mpc_chunk_kernel(const KernelParams p)
             float s_, c_;
             sincos_(eth, s_, c_);
             Q4 qd;
-            const float r = reward_state<NO, L, false>(d, wd, ex, ey, ev, s_, c_, bgd, qd, nullptr);
+            const float r = reward_state<NO, L, false, true>(d, wd, ex, ey, ev, s_, c_, bgd, qd, nullptr);
             G_ret = G_ret + r;
         }
 

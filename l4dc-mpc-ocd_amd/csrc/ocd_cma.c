@@ -6,9 +6,13 @@
  * episode kernel the numpy version of these steps costs ~70 us of call overhead per generation for ~2 us of
  * arithmetic (7 weights, 64 candidates); here they are three C calls.
  *
- * Algorithm: the textbook (mu/mu_w, lambda)-CMA-ES with default strategy parameters (N. Hansen, "The CMA Evolution
- * Strategy: A Tutorial", 2016), the same formulas as interact_drive/reward_design/cmaes.py (the numpy twin the
- * tests compare it with).  Candidates are m + sigma * C^(1/2) z with the SYMMETRIC square root, so the sample path
+ * Algorithm: the (mu/mu_w, lambda)-CMA-ES of N. Hansen, "The CMA Evolution Strategy: A Tutorial" (arXiv 1604.00772),
+ * with the default strategy parameters of its Table 1 -- recombination weights w'_i = ln((lambda+1)/2) - ln i over ALL
+ * lambda ranks (eq. 49), the positive ones normalised to sum 1, the negative ones scaled by min(alpha_mu^-,
+ * alpha_mueff^-, alpha_posdef^-) (eqs. 50-53) and used in the rank-mu update only ("active" CMA, eqs. 46-47: what pycma
+ * runs by default, CMA_active=True); ocd_cma_set_active(es, 0) drops the negative weights -- the same formulas as
+ * interact_drive/reward_design/cmaes.py (the numpy twin the tests compare it with; tests/test_cma_paper_constants.py
+ * types the constants of n = 7, lambda = 9 from the equations).  Candidates are m + sigma * C^(1/2) z with the SYMMETRIC square root, so the sample path
  * does not depend on the order or sign of the eigenvectors (numpy's LAPACK and the Jacobi sweep below give the same
  * candidates to rounding).  z comes from MT19937 + the polar method exactly as numpy.random.RandomState(seed)
  * .standard_normal does (bit-identical stream; tests/test_host_mirror.py).  The sampling sequence is not pycma's:
@@ -27,9 +31,10 @@
 #define MT_M 397
 
 struct ocd_cma {
-    int n, lam, mu;
+    int n, lam, mu, active;
     double sigma, mueff, cc, cs, c1, cmu, damps, chiN;
-    double *mean, *weights, *pc, *ps, *C, *B, *D, *sqrtC, *invsqrtC, *y, *best_x, *tmp, *work;
+    double wsum_all;          /* sum of all lambda weights as the C update sees them (1 without the negative ones) */
+    double *mean, *weights, *wraw, *wo, *pc, *ps, *C, *B, *D, *sqrtC, *invsqrtC, *y, *best_x, *tmp, *work;
     double best_f, max_d, min_d;
     double fit_best, fit_median, fit_worst;   /* of the population last told (non-finite costs excluded from best / worst) */
     int64_t gen, counteval, nonfinite_total;
@@ -179,6 +184,47 @@ static void decompose(ocd_cma *es)
 
 void ocd_cma_destroy(ocd_cma *es);
 
+/* eqs. 50-53: the final weights from w' -- positive ones / their sum; negative ones * min(alpha_mu^-, alpha_mueff^-,
+ * alpha_posdef^-) / the sum of their magnitudes (zero without the active update). */
+static void set_weights(ocd_cma *es)
+{
+    const int lam = es->lam, mu = es->mu;
+    double pos = 0.0, neg = 0.0, nsum = 0.0, nsq = 0.0;
+    for (int i = 0; i < mu; ++i) pos += es->wraw[i];
+    for (int i = mu; i < lam; ++i) { neg += fabs(es->wraw[i]); nsum += es->wraw[i]; nsq += es->wraw[i] * es->wraw[i]; }
+    const double mueff_neg = nsq > 0.0 ? nsum * nsum / nsq : 0.0;
+    const double a_mu = 1.0 + es->c1 / es->cmu;                                   /* eq. 50 */
+    const double a_mueff = 1.0 + 2.0 * mueff_neg / (es->mueff + 2.0);             /* eq. 51 */
+    const double a_posdef = (1.0 - es->c1 - es->cmu) / ((double)es->n * es->cmu); /* eq. 52 */
+    double a = a_mu < a_mueff ? a_mu : a_mueff;
+    if (a_posdef < a) a = a_posdef;
+    es->wsum_all = 0.0;
+    for (int i = 0; i < lam; ++i) {
+        if (i < mu) es->weights[i] = es->wraw[i] / pos;
+        else es->weights[i] = (es->active && neg > 0.0) ? a * es->wraw[i] / neg : 0.0;
+        es->wsum_all += es->weights[i];
+    }
+}
+
+/* The active update (negative recombination weights in the rank-mu term) on / off; on by default, as in pycma.  Only
+ * before the first tell. */
+int32_t ocd_cma_set_active(ocd_cma *es, int32_t on)
+{
+    if (!es || es->gen != 0) return -1;
+    es->active = on ? 1 : 0;
+    set_weights(es);
+    return 0;
+}
+
+int32_t ocd_cma_weights(const ocd_cma *es, double *w, double *consts)
+{
+    if (!es) return -1;
+    if (w) memcpy(w, es->weights, sizeof(double) * (size_t)es->lam);
+    if (consts) { consts[0] = es->mueff; consts[1] = es->cc; consts[2] = es->cs; consts[3] = es->c1; consts[4] = es->cmu;
+                  consts[5] = es->damps; consts[6] = es->chiN; consts[7] = es->wsum_all; }
+    return 0;
+}
+
 int32_t ocd_cma_create(int32_t n, const double *x0, double sigma0, int32_t popsize, uint32_t seed, ocd_cma **out)
 {
     if (!out) return -1;
@@ -191,28 +237,34 @@ int32_t ocd_cma_create(int32_t n, const double *x0, double sigma0, int32_t popsi
     if (es->lam < 2) { free(es); return -1; }
     es->mu = es->lam / 2;
     const size_t nn = (size_t)n * n;
-    const size_t total = (size_t)n * 6 + (size_t)es->mu + nn * 6 + (size_t)es->lam * n * 2;
+    const size_t total = (size_t)n * 6 + (size_t)es->lam * 3 + nn * 6 + (size_t)es->lam * n * 2;
     double *mem = (double *)calloc(total, sizeof(double));
     es->order = (int *)calloc((size_t)es->lam, sizeof(int));
     if (!mem || !es->order) { free(mem); free(es->order); free(es); return -1; }
     double *p = mem;
     es->mean = p; p += n; es->pc = p; p += n; es->ps = p; p += n; es->D = p; p += n; es->best_x = p; p += n; es->tmp = p; p += n;
-    es->weights = p; p += es->mu;
+    es->weights = p; p += es->lam;            /* [lam]: positive (first mu), then <= 0 */
+    es->wraw = p; p += es->lam;               /* w'_i of eq. 49 */
+    es->wo = p; p += es->lam;                 /* scratch of tell: the weights of this update (eq. 46) */
     es->C = p; p += nn; es->B = p; p += nn; es->sqrtC = p; p += nn; es->invsqrtC = p; p += nn; es->work = p; p += 2 * nn;
     es->y = p; p += (size_t)es->lam * n;
     es->z = p;
     memcpy(es->mean, x0, sizeof(double) * n);
     es->sigma = sigma0;
+    /* eq. 49: w'_i = ln((lambda + 1) / 2) - ln i, i = 1..lambda; positive exactly for i <= mu = floor(lambda / 2)
+     * (w'_(mu+1) = 0 when lambda is odd) */
     double wsum = 0.0, w2 = 0.0;
-    for (int i = 0; i < es->mu; ++i) { es->weights[i] = log(es->mu + 0.5) - log((double)(i + 1)); wsum += es->weights[i]; }
-    for (int i = 0; i < es->mu; ++i) { es->weights[i] /= wsum; w2 += es->weights[i] * es->weights[i]; }
-    es->mueff = 1.0 / w2;
+    for (int i = 0; i < es->lam; ++i) es->wraw[i] = log(((double)es->lam + 1.0) / 2.0) - log((double)(i + 1));
+    for (int i = 0; i < es->mu; ++i) { wsum += es->wraw[i]; w2 += es->wraw[i] * es->wraw[i]; }
+    es->mueff = wsum * wsum / w2;             /* Table 1: (sum_{i<=mu} w'_i)^2 / sum_{i<=mu} w'_i^2 */
     const double me = es->mueff, dn = (double)n;
-    es->cc = (4 + me / dn) / (dn + 4 + 2 * me / dn);
-    es->cs = (me + 2) / (dn + me + 5);
-    es->c1 = 2 / ((dn + 1.3) * (dn + 1.3) + me);
-    es->cmu = 2 * (me - 2 + 1 / me) / ((dn + 2) * (dn + 2) + me);
+    es->cc = (4 + me / dn) / (dn + 4 + 2 * me / dn);                 /* eq. 56 */
+    es->cs = (me + 2) / (dn + me + 5);                               /* eq. 55 */
+    es->c1 = 2 / ((dn + 1.3) * (dn + 1.3) + me);                     /* eq. 57, alpha_cov = 2 */
+    es->cmu = 2 * (me - 2 + 1 / me) / ((dn + 2) * (dn + 2) + me);    /* eq. 58, alpha_cov = 2 */
     if (es->cmu > 1 - es->c1) es->cmu = 1 - es->c1;
+    es->active = 1;
+    set_weights(es);
     const double dm = sqrt((me - 1) / (dn + 1)) - 1;
     es->damps = 1 + 2 * (dm > 0.0 ? dm : 0.0) + es->cs;
     es->chiN = sqrt(dn) * (1 - 1 / (4 * dn) + 1 / (21 * dn * dn));
@@ -356,13 +408,30 @@ int32_t ocd_cma_tell(ocd_cma *es, const double *X, const double *fitness)
     const int hsig = ps_norm / sqrt(1 - pow(1 - es->cs, 2.0 * (double)es->counteval / lam)) / es->chiN < 1.4 + 2.0 / (n + 1);
     const double cpc = hsig ? sqrt(es->cc * (2 - es->cc) * es->mueff) : 0.0;
     for (int i = 0; i < n; ++i) es->pc[i] = (1 - es->cc) * es->pc[i] + cpc * yw[i];
-    const double keep = (1 - es->c1 - es->cmu) + es->c1 * (hsig ? 0.0 : es->cc * (2 - es->cc));
+    /* eq. 47: C <- (1 + c1 delta(hsig) - c1 - cmu sum_j w_j) C + c1 pc pc^T + cmu sum_i w_i^o y_i y_i^T over all lambda
+     * ranks, w_i^o = w_i for w_i >= 0 and w_i * n / ||C^(-1/2) y_i||^2 for the negative ones (eq. 46) */
+    const double keep = (1 - es->c1 - es->cmu * es->wsum_all) + es->c1 * (hsig ? 0.0 : es->cc * (2 - es->cc));
+    const int n_rank = es->active ? lam : mu;
+    double *wo = es->wo;
+    for (int k = 0; k < n_rank; ++k) {
+        wo[k] = es->weights[k];
+        if (wo[k] < 0.0) {
+            const double *y = es->y + (size_t)es->order[k] * n;
+            double m2 = 0.0;
+            for (int i = 0; i < n; ++i) {
+                double a = 0.0;
+                for (int j = 0; j < n; ++j) a += es->invsqrtC[i * n + j] * y[j];
+                m2 += a * a;
+            }
+            wo[k] = m2 > 0.0 ? wo[k] * (double)n / m2 : 0.0;
+        }
+    }
     for (int i = 0; i < n; ++i)
         for (int j = i; j < n; ++j) {
             double rank_mu = 0.0;
-            for (int k = 0; k < mu; ++k) {
+            for (int k = 0; k < n_rank; ++k) {
                 const double *y = es->y + (size_t)es->order[k] * n;
-                rank_mu += es->weights[k] * y[i] * y[j];
+                rank_mu += wo[k] * y[i] * y[j];
             }
             const double c = keep * es->C[i * n + j] + es->c1 * es->pc[i] * es->pc[j] + es->cmu * rank_mu;
             es->C[i * n + j] = es->C[j * n + i] = c;        /* symmetric by construction */

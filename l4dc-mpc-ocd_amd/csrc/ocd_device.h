@@ -205,7 +205,10 @@ __device__ __forceinline__ bool needs_collision1(float x, float y, const BumpGeo
 // do_col / do_fence are WAVE-UNIFORM: false only when the caller has proved that, for every live lane,
 // the collision bumps / the fence thresholds are identically zero together with their gradients (see
 // needs_collision1 / needs_fence), so skipping them changes no bit of any result.
-template <int NO, int L, bool GRAD>
+// SCORED (value only): car.reward_fn(past_state, ...) as an episode is scored (mpc_ord.py:99) and as ocd_reward_batch returns
+// it -- the lane offset carries StraightLane.dist2median's y-term (y - p[1]) * n[1], n[1] = 0 (world.py:216-217): +-0 for a
+// finite y, NaN beyond; the planner's objective keeps (x - p[0]) * -1 (include/ocd.h ABI 3).
+template <int NO, int L, bool GRAD, bool SCORED = false>
 __device__ __forceinline__ float reward_state(const ocd_scenario_desc &d, const float (&w)[OCD_MAX_FEATURES],
                                               float x, float y, float v, float sn, float cn,
                                               const BumpGeom (&bg)[NO > 0 ? NO : 1], Q4 &q,
@@ -244,10 +247,12 @@ __device__ __forceinline__ float reward_state(const ocd_scenario_desc &d, const 
     for (int l = 0; l < L; ++l) {
         const float diff = x - d.lane_center[l];
         rl[l] = diff * -1.0f;
+        if (SCORED) rl[l] = rl[l] + (y - d.lane_origin_y) * d.lane_normal_y;
         const float d2 = rl[l] * rl[l];
         pl[l] = d2 * 10.0f;
         pmin = (l == 0) ? pl[0] : min_tf(pmin, pl[l]);
     }
+    static_assert(!(SCORED && GRAD), "the scored form has no gradient");
     int ntie_min = 0;
 #pragma unroll
     for (int l = 0; l < L; ++l) ntie_min += (pl[l] == pmin) ? 1 : 0;

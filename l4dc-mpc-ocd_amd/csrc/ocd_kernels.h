@@ -72,9 +72,13 @@ struct KernelParams {
     int32_t *launch_info;      // HOST pointer or nullptr: the launcher records its choice here (ocd_scenario_last_launch)
     int32_t dry_run;           // 1 = choose and record, launch nothing (ocd_scenario_plan_launch: no device needed)
     // ROLLOUT, indexed (ocd_rollout_indexed): episode `prob` = (weight row, init row, reset number) of ep_index[prob],
-    // instead of the flat (p, n, s) decomposition of ep_begin + prob; rows are clamped to [0, P_rows) / [0, N)
+    // instead of the flat (p, n, s) decomposition of ep_begin + prob.  A row outside [0, P_rows) / [0, N) / reset < 0 is a
+    // caller bug: an index in HOST memory is refused before the launch (ocd_api.hip); one in device memory is caught here --
+    // the episode reads row 0 (memory-safe), starts from a NaN ego (its return is NaN, never a plausible number) and
+    // index_error[0] gets 1 + the row's position (ocd_scenario_index_error reports it)
     const int32_t *ep_index;   // [n_problems, 3] or nullptr
     long long P_rows;          // rows of `weights` (indexed rollouts only)
+    int32_t *index_error;      // device-visible pinned word of the handle, or nullptr
     // fence_shape * fence_width < 1/80: smooth_threshold is 0/0 on the road in the reference itself; such a handle runs the
     // generic kernels only, every feature of every lane, BOTH sides of the fence as merging.py:80-81 writes them
     int32_t two_sided;
@@ -83,15 +87,19 @@ struct KernelParams {
 // Which (candidate row, init row, entry of the teleport cycle) episode `prob` of a rollout launch runs (both planner
 // kernels): the flat index e = ep_begin + prob = (p * N + n) * S + s of ocd_rollout_episodes, or row `prob` of the
 // caller's episode index (ocd_rollout_indexed: independent populations evaluated by one launch).
-__device__ __forceinline__ void episode_rows(const KernelParams &p, long long prob, long long &p_, long long &n_, int &tp_idx)
+// Returns false for an index row out of range (the caller poisons the episode: NaN ego state).
+__device__ __forceinline__ bool episode_rows(const KernelParams &p, long long prob, long long &p_, long long &n_, int &tp_idx)
 {
     const int period = p.d.teleport_period;
+    bool ok = true;
     if (p.ep_index) {
         const int32_t *ix = p.ep_index + 3 * prob;
         long long pr = ix[0], nr = ix[1], reset = ix[2];
-        pr = pr < 0 ? 0 : (pr >= p.P_rows ? p.P_rows - 1 : pr);
-        nr = nr < 0 ? 0 : (nr >= p.N ? p.N - 1 : nr);
-        reset = reset < 0 ? 0 : reset;
+        ok = pr >= 0 && pr < p.P_rows && nr >= 0 && nr < p.N && reset >= 0;
+        if (!ok) {
+            pr = 0; nr = 0; reset = 0;
+            if (p.index_error) p.index_error[0] = (int32_t)(prob < 0x7ffffffe ? prob + 1 : 0x7fffffff);
+        }
         p_ = pr; n_ = nr;
         tp_idx = (int)(reset % (period > 0 ? period : p.S));
     } else {
@@ -103,6 +111,7 @@ __device__ __forceinline__ void episode_rows(const KernelParams &p, long long pr
         // episode e of a sequential evaluation is reset number reset_phase + e
         tp_idx = period > 0 ? (int)((p.reset_phase + e_glob) % period) : (int)s_;
     }
+    return ok;
 }
 
 // the launchers' only way to start a planner kernel: nothing is launched in a dry run

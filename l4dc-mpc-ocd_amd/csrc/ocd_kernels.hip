@@ -194,9 +194,9 @@ mpc_kernel(const KernelParams p)
     int tp_idx = 0;                           // which entry of the teleport cycle applies to this episode
     if (p.mode == OCD_MODE_ROLLOUT && !p.from_state) {
         long long p_, n_;
-        episode_rows(p, prob, p_, n_, tp_idx);                // flat (p, n, s) index, or the caller's episode index
+        const bool row_ok = episode_rows(p, prob, p_, n_, tp_idx);   // flat (p, n, s) index, or the caller's episode index
         const float *ini = p.ego_states + 4 * n_;
-        ex = ini[0]; ey = ini[1]; ev = ini[2]; eth = ini[3];
+        ex = row_ok ? ini[0] : __builtin_nanf(""); ey = ini[1]; ev = ini[2]; eth = ini[3];
 #pragma unroll
         for (int j = 0; j < NO; ++j) {
             ox[j] = d.other_init[j][0]; oy[j] = d.other_init[j][1];
@@ -266,7 +266,7 @@ mpc_kernel(const KernelParams p)
             float s_, c_;
             sincos_(eth, s_, c_);
             Q4 qd;
-            const float r = reward_state<NO, L, false>(d, wd, ex, ey, ev, s_, c_, bgd, qd, nullptr, true, true, two_sided);
+            const float r = reward_state<NO, L, false, true>(d, wd, ex, ey, ev, s_, c_, bgd, qd, nullptr, true, true, two_sided);
             G_ret = G_ret + r;
         }
 
@@ -858,7 +858,7 @@ __global__ void reward_kernel(const KernelParams p, float *feats_out, float *rew
     float s_, c_;
     sincos_(ws[3], s_, c_);
     Q4 q;
-    const float r = reward_state<NO, L, false>(d, w, ws[0], ws[1], ws[2], s_, c_, bg, q,
+    const float r = reward_state<NO, L, false, true>(d, w, ws[0], ws[1], ws[2], s_, c_, bg, q,    // reward_fn: scored form
                                             feats_out ? feats_out + b * D : nullptr, true, true, p.two_sided != 0);
     if (reward_out) reward_out[b] = r;
 }

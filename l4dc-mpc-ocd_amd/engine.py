@@ -289,16 +289,18 @@ class Engine(DeviceOps):
         return out
 
     def rollout_indexed(self, init_states, cand_weights, episode_index, want_traj: bool = False,
-                        to_numpy: bool = True) -> Dict[str, object]:
+                        to_numpy: bool = True, check_index: bool = True) -> Dict[str, object]:
         """Independent populations in one launch (include/ocd.h: ocd_rollout_indexed; the reference's Pool over init
         groups, run_mpc_ord.py:83-90): episode i runs candidate row episode_index[i, 0] on init row [i, 1] as reset
         number [i, 2] of its own sequential evaluation.  init_states [N_rows, 4], cand_weights [P_rows, D] (fp32,
-        normalised), episode_index [E, 3] int32."""
+        normalised), episode_index [E, 3] int32.  An index row that names no candidate / init row raises ValueError here
+        (check_index=False leaves the check to the library: the kernel poisons that episode -- NaN return -- and
+        ocd_scenario_index_error raises after the wait)."""
         d = self.desc
         init = self._to_dev(init_states).reshape(-1, 4)
         w = self._to_dev(cand_weights).reshape(-1, max(d.n_features, 1))
         idx = np.ascontiguousarray(np.asarray(episode_index, dtype=np.int32).reshape(-1, 3))
-        if idx.size and (idx[:, 0].min() < 0 or idx[:, 0].max() >= w.shape[0] or idx[:, 1].min() < 0 or
+        if check_index and idx.size and (idx[:, 0].min() < 0 or idx[:, 0].max() >= w.shape[0] or idx[:, 1].min() < 0 or
                          idx[:, 1].max() >= init.shape[0] or idx[:, 2].min() < 0):
             raise ValueError("episode_index names a candidate / init row that does not exist, or a negative reset number")
         idx_dev = torch.as_tensor(idx).to(self.device)
@@ -313,6 +315,7 @@ class Engine(DeviceOps):
             out.update(traj=traj, ctrl=ctrl)
         if to_numpy:
             self._wait()
+            self._call(self.lib.ocd_scenario_index_error, self._h, None)   # a device-side out-of-range row raises here
             out = {k: self._host(v) for k, v in out.items()}
         return out
 

@@ -62,6 +62,11 @@ def describe(world, car, horizon: int, learning_rate: float = 0.1, n_iter: int =
             if not (float(lane.n[0]) == -1.0 and float(lane.n[1]) == 0.0):
                 raise NotImplementedError("only lanes running along +y (normal (-1, 0)) are compiled")
             d.lane_center[i] = float(lane.p[0])
+            if float(lane.p[1]) != float(lanes[0].p[1]):
+                raise NotImplementedError("lanes that start at different y (StraightLane.p[1]) are not compiled")
+        # dist2median's y-term (y - p[1]) * n[1] of the scored reward (world.py:216-217; include/ocd.h ABI 3)
+        d.lane_origin_y = float(lanes[0].p[1])
+        d.lane_normal_y = float(lanes[0].n[1])
         d.n_lanes = len(lanes)
         num_lanes = getattr(car, "num_lanes", len(lanes))
         d.fence_lo = np.float32(0.05 * num_lanes - 0.05)

@@ -119,16 +119,28 @@ def main(argv=None):
     # the optimisations are dealt over the ranks (optimize_cmaes_lockstep), a single optimisation shards its population
     import os
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    own_group = False
     if world_size > 1:
         import torch
         import torch.distributed as dist
+        if args.seed is None:
+            raise SystemExit("--seed is required under a launcher: every rank must draw the same init states and seeds")
         if not dist.is_initialized():
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
             dist.init_process_group(os.environ.get("OCD_DIST_BACKEND", "nccl"))
-        if args.seed is None:
-            raise SystemExit("--seed is required under a launcher: every rank must draw the same init states and seeds")
+            own_group = True
     env = envs[args.scenario]
     optimization_seed = np.random.randint(0, 2 ** 31) if world_size == 1 else (args.seed * 7919 + 1) % (2 ** 31)
+    try:
+        return _run(args, env, envs, optimization_seed)
+    finally:
+        if own_group:                                               # the group this call created ends with it
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.destroy_process_group()
+
+
+def _run(args, env, envs, optimization_seed):
     if args.seed is None:
         args.seed = optimization_seed
     env_seeds = [(args.seed * 1000000 + i) % (2 ** 32) for i in range(args.n_inits)]

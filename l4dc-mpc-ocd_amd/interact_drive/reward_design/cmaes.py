@@ -1,9 +1,13 @@
 """A compact (mu/mu_w, lambda)-CMA-ES with an ask/tell interface.
 
 The reference calls pycma's ``cma.evolution_strategy.fmin2`` (mpc_ord.py:41; pycma is an unpinned,
-un-vendored dependency, setup.py:6, and is not installed here).  This is the textbook algorithm
-(N. Hansen, "The CMA Evolution Strategy: A Tutorial", 2016, default strategy parameters) so that a
-whole population can be handed to the batched GPU fitness at once.  The sampling sequence is NOT
+un-vendored dependency, setup.py:6, and is not installed here).  This is the published algorithm
+(N. Hansen, "The CMA Evolution Strategy: A Tutorial", arXiv 1604.00772, default strategy parameters of
+its Table 1: recombination weights ln((lambda+1)/2) - ln i over all lambda ranks, eq. 49; the negative
+ones scaled per eqs. 50-53 and used in the rank-mu update only -- "active" CMA, eqs. 46-47, pycma's
+CMA_active=True default; ``active=False`` drops them) so that a whole population can be handed to the
+batched GPU fitness at once.  tests/test_cma_paper_constants.py types the constants of n = 7,
+lambda = 9 (the reference's shape) from the equations, not from either twin.  The sampling sequence is NOT
 pycma's: optimisation traces are "parity unpinned" (SURVEY.md 8c); the fitness values it is fed
 are bit-exact.
 
@@ -138,19 +142,29 @@ def _population_stats(fitness, order):
 
 
 class CMAES(_Termination):
-    def __init__(self, x0, sigma0, popsize=None, seed=1):
+    def __init__(self, x0, sigma0, popsize=None, seed=1, active=True):
         self.n = n = len(x0)
         self.mean = np.asarray(x0, dtype=np.float64).copy()
         self.sigma = float(sigma0)
-        self.lam = int(popsize) if popsize else 4 + int(3 * np.log(n))
-        self.mu = self.lam // 2
-        w = np.log(self.mu + 0.5) - np.log(np.arange(1, self.mu + 1))
-        self.weights = w / w.sum()
-        self.mueff = 1.0 / np.sum(self.weights ** 2)
-        self.cc = (4 + self.mueff / n) / (n + 4 + 2 * self.mueff / n)
-        self.cs = (self.mueff + 2) / (n + self.mueff + 5)
-        self.c1 = 2 / ((n + 1.3) ** 2 + self.mueff)
-        self.cmu = min(1 - self.c1, 2 * (self.mueff - 2 + 1 / self.mueff) / ((n + 2) ** 2 + self.mueff))
+        self.lam = lam = int(popsize) if popsize else 4 + int(3 * np.log(n))
+        self.mu = mu = self.lam // 2
+        self.active = bool(active)
+        # eq. 49: w'_i = ln((lambda + 1) / 2) - ln i for i = 1..lambda; positive exactly for i <= mu
+        wraw = np.log((lam + 1) / 2.0) - np.log(np.arange(1, lam + 1))
+        self.mueff = wraw[:mu].sum() ** 2 / np.sum(wraw[:mu] ** 2)                       # Table 1
+        self.cc = (4 + self.mueff / n) / (n + 4 + 2 * self.mueff / n)                    # eq. 56
+        self.cs = (self.mueff + 2) / (n + self.mueff + 5)                                # eq. 55
+        self.c1 = 2 / ((n + 1.3) ** 2 + self.mueff)                                      # eq. 57 (alpha_cov = 2)
+        self.cmu = min(1 - self.c1, 2 * (self.mueff - 2 + 1 / self.mueff) / ((n + 2) ** 2 + self.mueff))   # eq. 58
+        # eqs. 50-53: positive weights sum to 1; negative ones sum to -min(alpha_mu, alpha_mueff, alpha_posdef)
+        wneg = wraw[mu:]
+        mueff_neg = wneg.sum() ** 2 / np.sum(wneg ** 2) if np.any(wneg != 0) else 0.0
+        alpha = min(1 + self.c1 / self.cmu, 1 + 2 * mueff_neg / (self.mueff + 2),
+                    (1 - self.c1 - self.cmu) / (n * self.cmu))
+        neg_sum = np.abs(wneg).sum()
+        self.weights_all = np.concatenate([wraw[:mu] / wraw[:mu].sum(),
+                                           alpha * wneg / neg_sum if (self.active and neg_sum > 0) else 0.0 * wneg])
+        self.weights = self.weights_all[:mu]
         self.damps = 1 + 2 * max(0.0, np.sqrt((self.mueff - 1) / (n + 1)) - 1) + self.cs
         self.pc = np.zeros(n)
         self.ps = np.zeros(n)
@@ -216,8 +230,17 @@ class CMAES(_Termination):
         hsig = (ps_norm / np.sqrt(1 - (1 - self.cs) ** (2 * self.counteval / self.lam)) / self.chiN
                 < 1.4 + 2 / (n + 1))
         self.pc = (1 - self.cc) * self.pc + hsig * np.sqrt(self.cc * (2 - self.cc) * self.mueff) * yw
-        rank_mu = (ysel.T * self.weights) @ ysel
-        C = ((1 - self.c1 - self.cmu) * self.C
+        # eq. 47: all lambda ranks; a negative weight is rescaled by n / ||C^(-1/2) y_i||^2 (eq. 46)
+        if self.active:
+            yall = self._y[order]
+            wo = self.weights_all.copy()
+            neg = wo < 0
+            m2 = np.sum((yall[neg] @ self.invsqrtC) ** 2, axis=1)
+            wo[neg] = np.where(m2 > 0, wo[neg] * n / np.where(m2 > 0, m2, 1.0), 0.0)
+            rank_mu = (yall.T * wo) @ yall
+        else:
+            rank_mu = (ysel.T * self.weights) @ ysel
+        C = ((1 - self.c1 - self.cmu * self.weights_all.sum()) * self.C
              + self.c1 * (np.outer(self.pc, self.pc) + (1 - hsig) * self.cc * (2 - self.cc) * self.C)
              + self.cmu * rank_mu)
         # rank_mu is symmetric only up to rounding: keep C bit-symmetric, so that what eigh reads (the lower
@@ -346,6 +369,10 @@ def load_cma_library():
     lib.ocd_cma_destroy.argtypes = [C.c_void_p]
     lib.ocd_cma_popsize.restype = C.c_int32
     lib.ocd_cma_popsize.argtypes = [C.c_void_p]
+    lib.ocd_cma_set_active.restype = C.c_int32
+    lib.ocd_cma_set_active.argtypes = [C.c_void_p, C.c_int32]
+    lib.ocd_cma_weights.restype = C.c_int32
+    lib.ocd_cma_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ocd_cma_ask.restype = C.c_int32
     lib.ocd_cma_ask.argtypes = [C.c_void_p, C.c_void_p]
     lib.ocd_cma_prepare.restype = C.c_int32
@@ -400,7 +427,7 @@ def fitness_from_returns_native(returns: np.ndarray, P: int, N: int, S: int, out
 class NativeCMAES(_Termination):
     """The same ask / tell interface as CMAES over csrc/ocd_cma.c."""
 
-    def __init__(self, x0, sigma0, popsize=None, seed=1):
+    def __init__(self, x0, sigma0, popsize=None, seed=1, active=True):
         self.lib = load_cma_library()
         self.n = len(x0)
         x = np.ascontiguousarray(x0, dtype=np.float64)
@@ -409,6 +436,9 @@ class NativeCMAES(_Termination):
                                    C.byref(h)) != 0:
             raise ValueError("ocd_cma_create: bad arguments")
         self._h = h
+        self.active = bool(active)
+        if not active and self.lib.ocd_cma_set_active(h, 0) != 0:
+            raise RuntimeError("ocd_cma_set_active failed")
         self.lam = int(self.lib.ocd_cma_popsize(h))
         self.mu = self.lam // 2
         self._X = np.empty((self.lam, self.n), dtype=np.float64)
@@ -497,6 +527,13 @@ class NativeCMAES(_Termination):
         self.last_nonfinite, self.nonfinite_total = int(self._ss[8]), int(self._ss[9])
         why = {k: o.get(k) for i, k in enumerate(STOP_NAMES) if self._flags_c[i]}
         return int(done.value), why, bool(pending.value)
+
+    def strategy_parameters(self):
+        """(weights [lam], dict of mueff, cc, cs, c1, cmu, damps, chiN, weight_sum) as the native state holds them."""
+        w, c = np.empty(self.lam), np.empty(8)
+        if self.lib.ocd_cma_weights(self._h, w.ctypes.data, c.ctypes.data) != 0:
+            raise RuntimeError("ocd_cma_weights failed")
+        return w, dict(zip(("mueff", "cc", "cs", "c1", "cmu", "damps", "chiN", "weight_sum"), c.tolist()))
 
     def finish_tell(self):                                         # (the numpy twin defers work; nothing to do here)
         pass

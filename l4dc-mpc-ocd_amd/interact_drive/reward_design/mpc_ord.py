@@ -319,6 +319,9 @@ class MPC_ORD:
             print('eval', weights / np.linalg.norm(weights))
         return float(self.eval_population(weights[None])[0])
 
+    # pycma's CMA_active option (default True: negative recombination weights in the rank-mu update, tutorial eqs. 46-53)
+    cma_active = True
+
     def optimize_cmaes(self, seed=1, sigma0=0.1, popsize=None, maxiter=None, maxfevals=None, termination=None):
         """mpc_ord.py:33-45, with whole generations evaluated per launch.
 
@@ -336,7 +339,7 @@ class MPC_ORD:
         assert not self.done
         self.should_save_history = True
         self.eval_weights(self.designer_weights)                       # "Iteration 0" baseline
-        es = NativeCMAES(list(self.designer_weights), sigma0, popsize=popsize, seed=seed)   # csrc/ocd_cma.c
+        es = NativeCMAES(list(self.designer_weights), sigma0, popsize=popsize, seed=seed, active=self.cma_active)   # csrc/ocd_cma.c
         self.generation_seconds = []                               # per generation: ask ... termination test
         self.generation_wall_seconds = []                          # the same plus the interpreter's bookkeeping (history rows,
         self.fitness_seconds = []                                  #   counters): wall-clock of the loop / generations
@@ -590,6 +593,11 @@ def _lockstep_local(ords, seeds, sigma0s, popsize=None, maxiter=None, maxfevals=
         return res
     eng = engines[0]
     lib = load_cma_library()
+    if any(o.save_path is not None for o in ords):
+        # the reference dumps the history after EVERY evaluation (mpc_ord.py:146-148): with a save path a native call is one
+        # generation, so a crash loses at most the generation in flight (the single-run path refuses the native loop for the
+        # same reason).  Histories and pickles are the same either way.
+        chunk = 1
     ess = []
     for o, seed, sigma0 in zip(ords, seeds, sigma0s):                  # the head of optimize_cmaes, per run
         o.history.seed = seed
@@ -597,7 +605,7 @@ def _lockstep_local(ords, seeds, sigma0s, popsize=None, maxiter=None, maxfevals=
         assert not o.done
         o.should_save_history = True
         o.eval_weights(o.designer_weights)                             # "Iteration 0" baseline
-        ess.append(NativeCMAES(list(o.designer_weights), sigma0, popsize=popsize, seed=seed))
+        ess.append(NativeCMAES(list(o.designer_weights), sigma0, popsize=popsize, seed=seed, active=o.cma_active))
         o.generation_seconds, o.generation_wall_seconds, o.fitness_seconds = [], [], []
         o.host_split, o.n_resampled, o.stop_reason = {}, 0, {}
         o._eng_fixed = eng
@@ -721,25 +729,36 @@ def _lockstep_over_ranks(ords, seeds, sigma0s, popsize, maxiter, maxfevals, term
     for o in ords:
         o._local_only = True
     try:
-        local = None
-        if mine:
-            # (the distributed flag is read through dist.get_world_size(): the local call sees itself as unsharded
-            #  because every MPC_ORD it touches is marked _local_only)
-            local = _lockstep_local([ords[k] for k in mine], [seeds[k] for k in mine], [sigma0s[k] for k in mine],
-                                    popsize, maxiter, maxfevals, termination, chunk)
-        payload = {}
-        for j, k in enumerate(mine):
-            o = ords[k]
-            payload[k] = dict(history=[(np.asarray(w), float(r)) for w, r in o.history], seed=o.history.seed, iter=o.iter,
-                              stop_reason=o.stop_reason, n_nonfinite=list(o.n_nonfinite), n_resampled=o.n_resampled,
-                              generation_seconds=list(o.generation_seconds), best=np.asarray(local.best[j]),
-                              best_f=float(o.es.best_f))
-        stats = None if local is None else dict(generation_seconds=local.generation_seconds,
-                                                generation_wall_seconds=local.generation_wall_seconds,
-                                                episodes_per_generation=local.episodes_per_generation,
-                                                lockstep=local.lockstep, launch=local.launch)
-        everything = [None] * world
-        dist.all_gather_object(everything, (payload, stats))
+        # A rank whose runs fail must still reach the collective: the others would wait in all_gather_object until the
+        # backend's timeout.  The exception travels as text and every rank raises after the gather.
+        local, payload, stats, failure = None, {}, None, None
+        try:
+            if mine:
+                # (the distributed flag is read through dist.get_world_size(): the local call sees itself as unsharded
+                #  because every MPC_ORD it touches is marked _local_only)
+                local = _lockstep_local([ords[k] for k in mine], [seeds[k] for k in mine], [sigma0s[k] for k in mine],
+                                        popsize, maxiter, maxfevals, termination, chunk)
+            for j, k in enumerate(mine):
+                o = ords[k]
+                payload[k] = dict(history=[(np.asarray(w), float(r)) for w, r in o.history], seed=o.history.seed, iter=o.iter,
+                                  stop_reason=o.stop_reason, n_nonfinite=list(o.n_nonfinite), n_resampled=o.n_resampled,
+                                  generation_seconds=list(o.generation_seconds), best=np.asarray(local.best[j]),
+                                  best_f=float(o.es.best_f))
+            stats = None if local is None else dict(generation_seconds=local.generation_seconds,
+                                                    generation_wall_seconds=local.generation_wall_seconds,
+                                                    episodes_per_generation=local.episodes_per_generation,
+                                                    lockstep=local.lockstep, launch=local.launch)
+        except Exception as exc:                                       # noqa: BLE001 -- re-raised on every rank below
+            import traceback
+            failure = f"rank {rank}: {type(exc).__name__}: {exc}\n{traceback.format_exc()}"
+            payload, stats = {}, None
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (payload, stats, failure))
+        failures = [f for _, _, f in gathered if f]
+        if failures:
+            raise RuntimeError("optimize_cmaes_lockstep failed on " + "; ".join(f.splitlines()[0] for f in failures)
+                               + "\n" + failures[0])
+        everything = [(pl, st) for pl, st, _ in gathered]
     finally:
         for o in ords:
             o._local_only = False

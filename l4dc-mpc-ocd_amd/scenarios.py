@@ -271,6 +271,9 @@ def _set_lanes(d: abi.ScenarioDesc, centers: Sequence[float]) -> None:
         d.lane_center[i] = c
     # smooth_threshold(0.05*num_lanes, width=0.05): x_diff = x - (threshold - width) (math_utils.py:89)
     d.fence_lo = np.float32(0.05 * len(centers) - 0.05)
+    # StraightLane((x, -5.), (x, 10.), 0.1): p[1] = -5, n = (-m[1], m[0]) = (-1.0, 0.0) (world.py:150,157,184-187)
+    d.lane_origin_y = -5.0
+    d.lane_normal_y = 0.0
 
 
 def _set_other(d: abi.ScenarioDesc, j: int, init, friction: float,

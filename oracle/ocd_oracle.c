@@ -189,9 +189,12 @@ void ocd_oracle_dynamics_step(const float *st, const float *u, float dt, float d
 /* ---- reward of one world state and its gradient w.r.t. the ego state ---- */
 typedef struct { float qx, qy, qv, qth; } q4;
 
+/* scored: the reward as car.reward_fn(past_state, ...) evaluates it when an episode is scored (mpc_ord.py:99) -- the lane
+ * offset carries dist2median's y-term (world.py:216-217); 0: the planner's objective (naive_planner.py:33-77), which
+ * keeps r = (x - p0) * -1 -- the same bits for every finite y (include/ocd.h, ABI 3). */
 static float reward_state(const ocd_scenario_desc *d, const float *w,
                           float x, float y, float v, float sn, float cn,
-                          const float (*oxy)[2], float *feats, q4 *q)
+                          const float (*oxy)[2], float *feats, q4 *q, int scored)
 {
     if (d->reward_kind == OCD_REWARD_TARGET_SPEED) {
         /* r = 0; r -= (velocity - target) ** 2  (targetSpeedRewardMaximizerCar.py:50-56) */
@@ -228,6 +231,7 @@ static float reward_state(const ocd_scenario_desc *d, const float *w,
     for (int l = 0; l < L; ++l) {
         const float diff = x - d->lane_center[l];
         rl[l] = diff * -1.0f;
+        if (scored) rl[l] = rl[l] + (y - d->lane_origin_y) * d->lane_normal_y;   /* +-0, or NaN beyond the finite numbers */
         const float d2 = rl[l] * rl[l];
         phi[1 + l] = d2 * 10.0f;
     }
@@ -383,8 +387,10 @@ float ocd_oracle_reward(const ocd_scenario_desc *d, const float *ws, const float
     float s, c;
     ocd_ref_sincosf(ws[3], &s, &c);
     q4 q;
+    /* without a gradient this is reward_fn as the episode scoring and the heat map call it (scored form); with one, the
+     * planner's form */
     const float r = reward_state(d, w, ws[0], ws[1], ws[2], s, c, (const float (*)[2])oxy,
-                                 feats_out, grad_out ? &q : NULL);
+                                 feats_out, grad_out ? &q : NULL, grad_out == NULL);
     if (grad_out) { grad_out[0] = q.qx; grad_out[1] = q.qy; grad_out[2] = q.qv; grad_out[3] = q.qth; }
     return r;
 }
@@ -446,7 +452,7 @@ static float mpc_reward_core(const ocd_scenario_desc *d, const float *ego, const
             r = leaf_value(xn, yn, vn, sn, cn, grad ? &tape[t].q : NULL);
         else
             r = reward_state(d, w, xn, yn, vn, sn, cn, (const float (*)[2])oxy[t], NULL,
-                             grad ? &tape[t].q : NULL);
+                             grad ? &tape[t].q : NULL, 0);
         R = R + r;                              /* r = 0; r += reward_fn(...) */
         x = xn; y = yn; v = vn; th = thn; s = sn; c = cn;
         if (traj) { traj[4 * t] = x; traj[4 * t + 1] = y; traj[4 * t + 2] = v; traj[4 * t + 3] = th; }
@@ -538,6 +544,7 @@ static int check_desc(const ocd_scenario_desc *d)
     if (d->n_iter < 0 || d->episode_len < 0) return 0;
     if (d->n_samples < 1 || d->n_samples > OCD_MAX_SAMPLES) return 0;
     if (d->reward_kind == OCD_REWARD_LANE_FEATURES && (d->n_lanes < 1 || d->n_cars < 2)) return 0;
+    if (d->reward_kind == OCD_REWARD_LANE_FEATURES && !(d->lane_normal_y == 0.0f)) return 0;   /* lanes run along y */
     return 1;
 }
 

@@ -39,7 +39,9 @@ void ocd_oracle_dynamics_step(const float *state, const float *control, float dt
 
 /* ThreeLaneTestCar.features + reward (merging.py:32-83, linear_reward_car.py:49-55)
  * of one world state [C,4]; feats_out[D] and grad_out[4] (d reward / d ego state)
- * may be NULL.  Returns the reward. */
+ * may be NULL.  Returns the reward.  Without grad_out this is reward_fn as an episode is SCORED (mpc_ord.py:99; the
+ * lane offset carries dist2median's y-term, world.py:216-217: NaN for a non-finite y); with grad_out it is the planner's
+ * form (no y-term; identical for every finite y). */
 float ocd_oracle_reward(const ocd_scenario_desc *d, const float *world_state, const float *weights,
                         float *feats_out, float *grad_out);
 

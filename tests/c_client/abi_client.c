@@ -30,6 +30,7 @@ typedef int32_t (*fn_rollout)(const ocd_scenario *, const float *, const float *
 typedef int32_t (*fn_rollout_indexed)(const ocd_scenario *, const float *, int64_t, const float *, int64_t, const int32_t *, int64_t,
                                       float *, float *, float *, void *);
 typedef int32_t (*fn_sync)(void *);
+typedef int32_t (*fn_index_error)(const ocd_scenario *, int64_t *);
 typedef int32_t (*fn_cma_create)(int32_t, const double *, double, int32_t, uint32_t, ocd_cma **);
 typedef void (*fn_cma_destroy)(ocd_cma *);
 typedef int32_t (*fn_cma_run)(ocd_cma *, const ocd_cma_run_args *, int64_t *, int32_t *, int32_t *);
@@ -52,6 +53,7 @@ static void finite_horizon_h5(ocd_scenario_desc *d)
     d->teleport_state[0] = 10.0f;
     d->dt = 0.1f; d->dt_sq = (float)(0.1 * 0.1); d->learning_rate = 0.1f; d->ego_friction = 0.2f; d->target_speed = 1.0f;
     d->lane_center[0] = (float)(0.0 + -1.0 * 0.1 * 1); d->lane_center[1] = 0.0f; d->lane_center[2] = (float)(0.0 + -1.0 * 0.1 * -1);
+    d->lane_origin_y = -5.0f; d->lane_normal_y = 0.0f;                       /* StraightLane((0, -5), (0, 10), 0.1): world.py:150 */
     d->fence_lo = (float)(0.05 * 3 - 0.05); d->fence_width = 0.05f; d->fence_shape = (float)(5.0 / 0.05);
     d->bump_half_x = 0.08f; d->bump_half_y = 0.15f;
     d->other_init[0][0] = 0.0f; d->other_init[0][1] = -0.6f; d->other_init[0][2] = 0.5f; d->other_init[0][3] = (float)(M_PI / 2);
@@ -79,6 +81,7 @@ int main(int argc, char **argv)
     SYM(hip, fn_scenario_destroy, ocd_scenario_destroy)
     SYM(hip, fn_rollout, ocd_rollout_episodes)
     SYM(hip, fn_rollout_indexed, ocd_rollout_indexed)
+    SYM(hip, fn_index_error, ocd_scenario_index_error)
     SYM(hip, fn_sync, ocd_stream_synchronize)
     SYM(cma, fn_cma_create, ocd_cma_create)
     SYM(cma, fn_cma_destroy, ocd_cma_destroy)
@@ -146,6 +149,38 @@ int main(int argc, char **argv)
         for (int e = 0; e < 6; ++e)
             if (memcmp(&back[e], &ret[5 - e], sizeof(float))) { fprintf(stderr, "indexed episode %d differs from the flat call\n", e); return 1; }
         printf("indexed rollout equals the flat call on 6 episodes\n");
+        /* an index row that names no candidate is an ERROR, not a clamp (ABI 3).  Pinned host memory: refused before
+         * anything is launched, the row named in the message */
+        idx_pin[4 * 3 + 0] = 2;                                    /* row 4: candidate 2 of 2 */
+        int32_t st = ocd_rollout_indexed(scn, init_dev, 3, w_dev, 2, idx_pin, 6, ret_dev, NULL, NULL, NULL);
+        if (st != OCD_ERR_INVALID_ARG || !strstr(ocd_last_error(), "row 4")) { fprintf(stderr, "bad pinned index: status %d (%s)\n", st, ocd_last_error()); return 1; }
+        /* device memory: the kernel finds it -- that episode's return is NaN, the others are untouched, and the handle
+         * reports the row after the wait */
+        int32_t *idx_dev;
+        int64_t bad_row = -2;
+        if (hipMalloc((void **)&idx_dev, sizeof idx)) return 1;
+        idx[4][1] = -1;                                            /* row 4: init row -1 */
+        hipMemcpy(idx_dev, idx, sizeof idx, 1);
+        if (ocd_scenario_index_error(scn, &bad_row) != OCD_OK || bad_row != -1) { fprintf(stderr, "index error before any device index\n"); return 1; }
+        if (ocd_rollout_indexed(scn, init_dev, 3, w_dev, 2, idx_dev, 6, ret_dev, NULL, NULL, NULL) != OCD_OK) { fprintf(stderr, "device index: %s\n", ocd_last_error()); return 1; }
+        if (ocd_stream_synchronize(NULL) != OCD_OK) return 1;
+        hipMemcpy(back, ret_dev, sizeof back, 2);
+        for (int e = 0; e < 6; ++e)
+            if (e == 4 ? back[e] == back[e] : memcmp(&back[e], &ret[5 - e], sizeof(float))) { fprintf(stderr, "device index, episode %d: %g\n", e, back[e]); return 1; }
+        st = ocd_scenario_index_error(scn, &bad_row);
+        if (st != OCD_ERR_INVALID_ARG || bad_row != 4) { fprintf(stderr, "index error: status %d row %lld\n", st, (long long)bad_row); return 1; }
+        if (ocd_scenario_index_error(scn, &bad_row) != OCD_OK) { fprintf(stderr, "the index error was not cleared by reporting it\n"); return 1; }
+        /* unreported, the next indexed launch on the handle refuses */
+        if (ocd_rollout_indexed(scn, init_dev, 3, w_dev, 2, idx_dev, 6, ret_dev, NULL, NULL, NULL) != OCD_OK) return 1;
+        if (ocd_stream_synchronize(NULL) != OCD_OK) return 1;
+        idx[4][1] = 1;
+        hipMemcpy(idx_dev, idx, sizeof idx, 1);
+        st = ocd_rollout_indexed(scn, init_dev, 3, w_dev, 2, idx_dev, 6, ret_dev, NULL, NULL, NULL);
+        if (st != OCD_ERR_INVALID_ARG || !strstr(ocd_last_error(), "row 4")) { fprintf(stderr, "sticky index error: status %d (%s)\n", st, ocd_last_error()); return 1; }
+        if (ocd_rollout_indexed(scn, init_dev, 3, w_dev, 2, idx_dev, 6, ret_dev, NULL, NULL, NULL) != OCD_OK) return 1;
+        if (ocd_stream_synchronize(NULL) != OCD_OK || ocd_scenario_index_error(scn, NULL) != OCD_OK) return 1;
+        hipFree(idx_dev);
+        printf("out-of-range index rows are errors: pinned index refused, device index NaN + reported\n");
     }
     /* one native CMA-ES generation: population 4, the launch and the wait as function pointers, pinned buffers */
     ocd_cma *es = NULL;

@@ -64,6 +64,9 @@ def test_c_client_episodes_and_native_generation_match_the_oracle(client, oracle
     got = np.array([float(x) for x in line(r.stdout, "returns")], dtype=np.float32)
     assert np.array_equal(got, want.ravel())
     assert "indexed rollout equals the flat call on 6 episodes" in r.stdout      # ocd_rollout_indexed, reverse order, in C
+    # ABI 3: an index row that names no candidate / init row is OCD_ERR_INVALID_ARG (host index: before the launch; device
+    # index: NaN return + ocd_scenario_index_error), never a clamp
+    assert "out-of-range index rows are errors: pinned index refused, device index NaN + reported" in r.stdout
     # the generation: the rows the C loop normalised into pinned memory, the costs it told
     gen = line(r.stdout, "generation")
     assert gen[:6] == ["done", "1", "pending", "0", "maxiter", "1"] and gen[6] == "costs"

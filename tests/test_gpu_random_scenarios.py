@@ -40,6 +40,8 @@ def random_scenario(rng, H, NO, L):
     centers = np.sort(rng.uniform(-0.15, 0.15, L))
     for i in range(L):
         d.lane_center[i] = centers[i]
+    d.lane_origin_y = float(rng.uniform(-6.0, -4.0))          # StraightLane.p[1]; the normal's y component stays 0
+    d.lane_normal_y = 0.0 if rng.random() < 0.5 else -0.0
     d.fence_lo = np.float32(rng.uniform(0.0, 0.15))
     d.fence_width = float(rng.uniform(0.02, 0.08))
     d.fence_shape = float(np.float32(5.0 / float(np.float32(d.fence_width))))

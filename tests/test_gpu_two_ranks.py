@@ -17,12 +17,24 @@ BENCH = os.path.join(ROOT, "bench.py")
 
 
 def run(args, timeout=600):
+    """One bench.py run: the printed line stays under its cap (N > 1 too), and the FULL record -- the side file the line
+    names -- is what the assertions below read."""
+    import tempfile
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, env=env, timeout=timeout)
-    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    return json.loads(lines[0])
+    with tempfile.TemporaryDirectory() as tmp:
+        env["OCD_BENCH_DETAIL"] = os.path.join(tmp, "detail.json")
+        r = subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, env=env, timeout=timeout)
+        assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1 and len(lines[0]) < 8192, r.stdout[-2000:]
+        line = json.loads(lines[0])
+        assert line["detail"] == env["OCD_BENCH_DETAIL"]
+        with open(line["detail"]) as f:
+            full = json.load(f)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype"):
+        assert line[k] == full[k], k
+    assert line["roofline"]["kernel_ms"] == full["roofline"]["kernel_ms"]
+    return full
 
 
 COMMON = ["--steps", "3", "--warmup", "1", "--no-extras", "--no-cpu-baseline"]

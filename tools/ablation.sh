@@ -15,7 +15,7 @@ if [ "$1" = "build" ]; then
     for arm in "nopk:-DOCD_NO_PACKED" "noasm:-DOCD_NO_ASM_CHAINS" "neither:-DOCD_NO_PACKED -DOCD_NO_ASM_CHAINS"; do
         name=${arm%%:*}; defs=${arm#*:}
         /opt/rocm/bin/hipcc $FLAGS $defs -c "$CSRC/ocd_kernels.hip" -o /tmp/abl_$name.o
-        /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$CSRC/libocd_hip_abl_$name.so" /tmp/abl_$name.o "$CSRC/ocd_chunk_kernel.o" "$CSRC/ocd_api.o"
+        /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-z,defs -o "$CSRC/libocd_hip_abl_$name.so" /tmp/abl_$name.o "$CSRC/ocd_chunk_kernel.o" "$CSRC/ocd_api.o" "$CSRC/ocd_debug_kernels.o"
         echo built $name
     done
     # the shared-SIMD builds of the chunked kernel without their work-item lists (round 5): every (lane, step) pair through reward_one

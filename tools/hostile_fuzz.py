@@ -67,6 +67,10 @@ def main():
         d.bump_half_y = pick(rng, d.bump_half_y, 1e-12, 1e8, 0.4)
         for i in range(L):
             d.lane_center[i] = pick(rng, d.lane_center[i], 1e-9, 1e6, 0.2) * float(rng.choice([-1, 1]))
+        # StraightLane.p[1] of the scored reward's y-term (ABI 3): absurd now and then, +-inf / NaN rarely (every score NaN)
+        d.lane_origin_y = pick(rng, d.lane_origin_y, 1e-6, 3e38, 0.1) * float(rng.choice([-1, 1]))
+        if rng.random() < 0.02:
+            d.lane_origin_y = float(rng.choice([np.inf, -np.inf, np.nan]))
         for j in range(NO):
             d.other_friction[j] = pick(rng, d.other_friction[j], 1e-6, 1e4, 0.2)
             if rng.random() < 0.12:                                  # scripted controls that send the car to infinity / NaN
