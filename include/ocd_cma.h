@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 #define OCD_CMA_MAX_DIM 64
-#define OCD_CMA_ABI_VERSION 6      /* 6: the tutorial's weights ln((lambda+1)/2) - ln i over all ranks, active update on by default, set_active, weights; 2: tell returns the non-finite count; resample, stop_state, abi_version; 3: normalise_weights; 4: stop, run; 5: 12 stop rules (noeffectaxis, noeffectcoord), add_evals, run_many */
+#define OCD_CMA_ABI_VERSION 7      /* 7: run_many in groups on several streams (n_groups, streams); 6: the tutorial's weights ln((lambda+1)/2) - ln i over all ranks, active update on by default, set_active, weights; 2: tell returns the non-finite count; resample, stop_state, abi_version; 3: normalise_weights; 4: stop, run; 5: 12 stop rules (noeffectaxis, noeffectcoord), add_evals, run_many */
 #define OCD_CMA_N_STOP 12          /* termination rules of ocd_cma_stop */
 
 typedef struct ocd_cma ocd_cma;
@@ -159,10 +159,18 @@ typedef struct ocd_cma_many_args {
     int32_t *stop_flags;          /* [R, OCD_CMA_N_STOP] out: the rules that ended run r in this call */
     uint8_t *pending_nan;         /* [R] out: run r's last generation is evaluated (X, cost, history rows) but NOT told: a
                                    * cost is NaN -- the caller redraws (ocd_cma_resample), tells it, and calls again */
+    /* ---- ABI 7 ---- */
+    int32_t n_groups;             /* 0 / 1: one launch per generation on `stream`.  G > 1 (<= 8): the runs are dealt to G groups of
+                                   * neighbouring runs, group k launches on streams[k]; each group cycles wait -> tell -> ask -> launch
+                                   * by itself and the groups take turns, so one group's host work runs under the others' kernels
+                                   * (for launches of at most one wavefront per SIMD: they run side by side) */
+    int32_t reserved;
+    void *const *streams;         /* [n_groups] HIP streams, ordered after whatever produced init_dev */
 } ocd_cma_many_args;
 
-/* Returns after max_generations, when no run is active any more, or right after a generation in which some run got a
- * NaN cost (pending_nan).  *generations_done = lockstep generations executed in this call. */
+/* Returns after max_generations, when no run is active any more, or once a run got a NaN cost (pending_nan) and whatever
+ * was already launched has been reduced and told (with several groups that can be one more generation of the other groups:
+ * `evaluated` says who took part in which).  *generations_done = lockstep generations executed in this call. */
 int32_t ocd_cma_run_many(ocd_cma *const *es, const ocd_cma_many_args *a, int64_t *generations_done);
 
 /* K fitness evaluations of one fixed population back to back -- launch (a->rollout on the P rows of a->w_pinned, taken

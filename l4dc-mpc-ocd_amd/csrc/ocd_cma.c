@@ -720,10 +720,27 @@ int32_t ocd_cma_run(ocd_cma *es, const ocd_cma_run_args *a, int64_t *generations
  * prepare, tell, stop, in that order, on its own state and random stream), so its history is bit for bit the history of
  * the run alone; a run that stops drops out of the index, a run with a NaN cost is handed back untold (pending_nan[r])
  * for the caller's rejection sampling while the others are told. */
-static void build_index(const ocd_cma_many_args *a, ocd_cma *const *es, int64_t *ret_off, int64_t *E_out)
+/* The runs are dealt to G = a->n_groups groups of neighbouring runs (1 when the field is 0), each with its own stream and
+ * its own region of the index / returns buffers.  A group cycles  wait -> reduce -> tell -> stop -> ask -> normalise ->
+ * launch -> (next deviates, history rows)  by itself, and the groups take turns: while one group's host work runs (28 tells
+ * + asks of the reference's shape: ~0.1 ms per generation after a 1.15 ms kernel), the other groups' kernels are still
+ * on the GPU -- launches of at most one wavefront per SIMD, side by side on different SIMDs (round 6).  With one group the
+ * call sequence is exactly round 5's.  A run's own sequence of calls does not depend on the grouping. */
+#define OCD_CMA_MAX_GROUPS 8
+typedef struct {
+    int r0, r1;               /* runs [r0, r1) */
+    void *stream;
+    int64_t e_cap0;           /* first row of the group's region in index_pinned / ret_pinned */
+    int64_t E;                /* episodes of its current index */
+    int dirty;                /* the index must be rebuilt (a run dropped out) */
+    int in_flight;            /* a launch of generation `gen` is on the stream, not yet reduced / told */
+    int64_t gen;              /* the generation of that launch */
+} cma_group;
+
+static void build_group_index(const ocd_cma_many_args *a, ocd_cma *const *es, cma_group *gr, int64_t *ret_off)
 {
-    int64_t e = 0;
-    for (int r = 0; r < a->R; ++r) {
+    int64_t e = gr->e_cap0;
+    for (int r = gr->r0; r < gr->r1; ++r) {
         ret_off[r] = -1;
         if (!a->active[r]) continue;
         ret_off[r] = e;
@@ -738,7 +755,77 @@ static void build_index(const ocd_cma_many_args *a, ocd_cma *const *es, int64_t 
                     row[2] = (int32_t)(phase + flat);
                 }
     }
-    *E_out = e;
+    gr->E = e - gr->e_cap0;
+}
+
+/* ask -> normalise -> (index) -> launch -> the host work that overlaps the kernel, for the active runs of one group and
+ * generation g; t[0..3] += ask, normalise, launch, overlapped seconds */
+static int32_t group_launch(ocd_cma *const *es, const ocd_cma_many_args *a, cma_group *gr, int64_t g, int n, int64_t *ret_off,
+                            double *t)
+{
+    int n_active = 0;
+    for (int r = gr->r0; r < gr->r1; ++r) n_active += a->active[r] != 0;
+    if (!n_active) return 0;
+    const double t0 = now_s();
+    for (int r = gr->r0; r < gr->r1; ++r)
+        if (a->active[r] && ocd_cma_ask(es[r], a->X[r]) != 0) return -1;
+    const double t1 = now_s();
+    for (int r = gr->r0; r < gr->r1; ++r)
+        if (a->active[r] && ocd_normalise_weights(a->X[r], es[r]->lam, n, a->normalise_variant,
+                                                  a->w_pinned + (size_t)a->run_p0[r] * n) != 0) return -1;
+    if (gr->dirty) { build_group_index(a, es, gr, ret_off); gr->dirty = 0; }
+    const double t2 = now_s();
+    const int32_t st = a->rollout(a->scn, a->init_dev, a->N_rows, a->w_pinned, a->P_rows, a->index_pinned + 3 * gr->e_cap0, gr->E,
+                                  a->ret_pinned + gr->e_cap0, NULL, NULL, gr->stream);
+    if (st != 0) return st < 0 ? st : -1;
+    gr->in_flight = 1;
+    gr->gen = g;
+    if (a->episodes_launched) a->episodes_launched[g] += gr->E;
+    const double t3 = now_s();
+    for (int r = gr->r0; r < gr->r1; ++r) {                     /* while the GPU works */
+        if (!a->active[r]) continue;
+        if (a->evaluated) a->evaluated[(size_t)g * a->R + r] = 1;
+        ocd_cma_prepare(es[r]);
+        if (a->hist_w)
+            for (int k = 0; k < es[r]->lam; ++k)
+                row_normalise_once(a->X[r] + (size_t)k * n, n, a->normalise_variant,
+                                   a->hist_w + ((size_t)g * a->P_rows + a->run_p0[r] + k) * n);
+    }
+    const double t4 = now_s();
+    t[0] += t1 - t0; t[1] += t2 - t1; t[2] += t3 - t2; t[3] += t4 - t3;
+    return 0;
+}
+
+/* wait -> reduce -> tell -> stop for the group's launch in flight; t[0..2] += wait, reduce, tell seconds;
+ * *any_pending |= some run of the group got a NaN cost (left evaluated, not told) */
+static int32_t group_finish(ocd_cma *const *es, const ocd_cma_many_args *a, cma_group *gr, const int64_t *ret_off, double *t,
+                            int *any_pending)
+{
+    const int64_t g = gr->gen;
+    const double t0 = now_s();
+    if (a->sync(gr->stream) != 0) return -1;
+    gr->in_flight = 0;
+    const double t1 = now_s();
+    for (int r = gr->r0; r < gr->r1; ++r) {
+        if (!a->active[r]) continue;
+        const int lam = es[r]->lam;
+        if (ocd_fitness_from_returns(a->ret_pinned + ret_off[r], lam, a->run_N[r], a->S, a->cost[r]) != 0) return -1;
+        if (a->hist_cost) memcpy(a->hist_cost + (size_t)g * a->P_rows + a->run_p0[r], a->cost[r], sizeof(double) * (size_t)lam);
+        int any_nan = 0;
+        for (int k = 0; k < lam; ++k) any_nan |= isnan(a->cost[r][k]);
+        if (any_nan) { a->pending_nan[r] = 1; *any_pending = 1; }
+    }
+    const double t2 = now_s();
+    for (int r = gr->r0; r < gr->r1; ++r) {
+        if (!a->active[r] || a->pending_nan[r]) continue;
+        const int32_t nonfinite = ocd_cma_tell(es[r], a->X[r], a->cost[r]);
+        if (nonfinite < 0) return -1;
+        if (a->nonfinite) a->nonfinite[(size_t)g * a->R + r] = nonfinite;
+        if (ocd_cma_stop(es[r], a->stop_opts, a->stop_flags + (size_t)r * OCD_CMA_N_STOP) > 0) { a->active[r] = 0; gr->dirty = 1; }
+    }
+    const double t3 = now_s();
+    t[0] += t1 - t0; t[1] += t2 - t1; t[2] += t3 - t2;
+    return 0;
 }
 
 int32_t ocd_cma_run_many(ocd_cma *const *es, const ocd_cma_many_args *a, int64_t *generations_done)
@@ -747,7 +834,8 @@ int32_t ocd_cma_run_many(ocd_cma *const *es, const ocd_cma_many_args *a, int64_t
     if (a->R < 1 || a->R > OCD_CMA_MAX_RUNS || !a->rollout || !a->sync || !a->w_pinned || !a->ret_pinned || !a->index_pinned ||
         !a->run_n0 || !a->run_N || !a->run_p0 || !a->active || !a->X || !a->cost || !a->stop_flags || !a->pending_nan ||
         !a->stop_opts || a->S < 1 || a->N_rows < 1 || a->P_rows < 1 || a->max_generations < 0 ||
-        a->normalise_variant < 0 || a->normalise_variant > 1) return -1;
+        a->normalise_variant < 0 || a->normalise_variant > 1 || a->n_groups < 0 || a->n_groups > OCD_CMA_MAX_GROUPS ||
+        (a->n_groups > 1 && !a->streams)) return -1;
     const int R = a->R;
     int n = 0;
     for (int r = 0; r < R; ++r) {
@@ -759,64 +847,78 @@ int32_t ocd_cma_run_many(ocd_cma *const *es, const ocd_cma_many_args *a, int64_t
         for (int i = 0; i < OCD_CMA_N_STOP; ++i) a->stop_flags[(size_t)r * OCD_CMA_N_STOP + i] = 0;
     }
     *generations_done = 0;
+    /* the groups: neighbouring runs, each group's region of the index / returns buffers sized for all of its runs */
+    int G = a->n_groups > 1 ? a->n_groups : 1;
+    if (G > R) G = R;
+    cma_group grp[OCD_CMA_MAX_GROUPS];
     int64_t ret_off[OCD_CMA_MAX_RUNS];
-    int64_t E = 0;
-    int dirty = 1;
-    for (int64_t g = 0; g < a->max_generations; ++g) {
+    {
+        int64_t e = 0;
+        for (int k = 0; k < G; ++k) {
+            cma_group *gr = &grp[k];
+            gr->r0 = (int)((int64_t)R * k / G);
+            gr->r1 = (int)((int64_t)R * (k + 1) / G);
+            gr->stream = G > 1 ? a->streams[k] : a->stream;
+            gr->e_cap0 = e;
+            gr->E = 0; gr->dirty = 1; gr->in_flight = 0; gr->gen = 0;
+            for (int r = gr->r0; r < gr->r1; ++r) e += (int64_t)es[r]->lam * a->run_N[r] * a->S;
+        }
+    }
+    if (a->max_generations == 0) return 0;
+    {
         int n_active = 0;
         for (int r = 0; r < R; ++r) n_active += a->active[r] != 0;
         if (!n_active) return 0;
+    }
+    int32_t err = 0;
+    int drain = 0;                             /* a run is pending (NaN cost): finish what is in flight, launch nothing more */
+    double t_prev = now_s();
+    double tl[4] = {0, 0, 0, 0};               /* the launches made for the generation that follows */
+    if (a->episodes_launched) a->episodes_launched[0] = 0;
+    if (a->evaluated) memset(a->evaluated, 0, (size_t)R);
+    for (int k = 0; k < G; ++k) {
+        err = group_launch(es, a, &grp[k], 0, n, ret_off, tl);
+        if (err != 0) goto fail;
+    }
+    for (int64_t g = 0; g < a->max_generations; ++g) {
         double *sg = a->seconds ? a->seconds + 8 * g : NULL;
-        const double t0 = now_s();
-        for (int r = 0; r < R; ++r)
-            if (a->active[r] && ocd_cma_ask(es[r], a->X[r]) != 0) return -1;
-        const double t1 = now_s();
-        for (int r = 0; r < R; ++r)
-            if (a->active[r] && ocd_normalise_weights(a->X[r], es[r]->lam, n, a->normalise_variant,
-                                                      a->w_pinned + (size_t)a->run_p0[r] * n) != 0) return -1;
-        if (dirty) { build_index(a, es, ret_off, &E); dirty = 0; }
-        const double t2 = now_s();
-        const int32_t st = a->rollout(a->scn, a->init_dev, a->N_rows, a->w_pinned, a->P_rows, a->index_pinned, E,
-                                      a->ret_pinned, NULL, NULL, a->stream);
-        if (st != 0) return st < 0 ? st : -1;
-        if (a->episodes_launched) a->episodes_launched[g] = E;
-        const double t3 = now_s();
-        for (int r = 0; r < R; ++r) {                     /* while the GPU works */
-            if (a->evaluated) a->evaluated[(size_t)g * R + r] = a->active[r];
-            if (!a->active[r]) continue;
-            ocd_cma_prepare(es[r]);
-            if (a->hist_w)
-                for (int k = 0; k < es[r]->lam; ++k)
-                    row_normalise_once(a->X[r] + (size_t)k * n, n, a->normalise_variant,
-                                       a->hist_w + ((size_t)g * a->P_rows + a->run_p0[r] + k) * n);
+        double tf[3] = {0, 0, 0};
+        double tn[4] = {0, 0, 0, 0};
+        int any_in_flight = 0;
+        if (g + 1 < a->max_generations) {                   /* (group_launch marks who takes part in g + 1) */
+            if (a->episodes_launched) a->episodes_launched[g + 1] = 0;
+            if (a->evaluated) memset(a->evaluated + (size_t)(g + 1) * R, 0, (size_t)R);
         }
-        const double t4 = now_s();
-        if (a->sync(a->stream) != 0) return -1;
-        const double t5 = now_s();
-        int any_pending = 0;
-        for (int r = 0; r < R; ++r) {
-            if (!a->active[r]) continue;
-            const int lam = es[r]->lam;
-            if (ocd_fitness_from_returns(a->ret_pinned + ret_off[r], lam, a->run_N[r], a->S, a->cost[r]) != 0) return -1;
-            if (a->hist_cost) memcpy(a->hist_cost + (size_t)g * a->P_rows + a->run_p0[r], a->cost[r], sizeof(double) * (size_t)lam);
-            int any_nan = 0;
-            for (int k = 0; k < lam; ++k) any_nan |= isnan(a->cost[r][k]);
-            if (any_nan) { a->pending_nan[r] = 1; any_pending = 1; }
+        for (int k = 0; k < G; ++k) {
+            cma_group *gr = &grp[k];
+            if (!gr->in_flight || gr->gen != g) continue;   /* (a group without active runs has nothing in flight) */
+            any_in_flight = 1;
+            int pend = 0;
+            err = group_finish(es, a, gr, ret_off, tf, &pend);
+            if (err != 0) goto fail;
+            if (pend) drain = 1;
+            /* this group's next generation goes out before the next group is waited for: its kernel runs while the others'
+             * results are reduced and told */
+            if (!drain && g + 1 < a->max_generations) {
+                err = group_launch(es, a, gr, g + 1, n, ret_off, tn);
+                if (err != 0) goto fail;
+            }
         }
-        const double t6 = now_s();
-        for (int r = 0; r < R; ++r) {
-            if (!a->active[r] || a->pending_nan[r]) continue;
-            const int32_t nonfinite = ocd_cma_tell(es[r], a->X[r], a->cost[r]);
-            if (nonfinite < 0) return -1;
-            if (a->nonfinite) a->nonfinite[(size_t)g * R + r] = nonfinite;
-            if (ocd_cma_stop(es[r], a->stop_opts, a->stop_flags + (size_t)r * OCD_CMA_N_STOP) > 0) { a->active[r] = 0; dirty = 1; }
-        }
-        const double t7 = now_s();
-        if (sg) { sg[1] = t1 - t0; sg[2] = t2 - t1; sg[3] = t3 - t2; sg[4] = t4 - t3; sg[5] = t5 - t4; sg[6] = t6 - t5; sg[7] = t7 - t6; sg[0] = t7 - t0; }
+        if (!any_in_flight) break;                          /* no run was active in generation g */
+        const double t_now = now_s();
+        if (sg) { sg[1] = tl[0]; sg[2] = tl[1]; sg[3] = tl[2]; sg[4] = tl[3]; sg[5] = tf[0]; sg[6] = tf[1]; sg[7] = tf[2]; sg[0] = t_now - t_prev; }
+        t_prev = t_now;
+        for (int i = 0; i < 4; ++i) tl[i] = tn[i];
         *generations_done = g + 1;
-        if (any_pending) return 0;            /* the caller redraws, tells those runs, and calls again */
+        int still = 0;
+        for (int k = 0; k < G; ++k) still |= grp[k].in_flight;
+        if (!still) break;                                  /* nothing launched for g + 1: pending, the cap, or no active run */
     }
     return 0;
+fail:                                          /* nothing stays in flight behind an error: the caller frees the buffers */
+    for (int k = 0; k < G; ++k)
+        if (grp[k].in_flight) { (void)a->sync(grp[k].stream); grp[k].in_flight = 0; }
+    return err;
 }
 
 /* K fitness evaluations of one fixed population, back to back: launch, wait, float64 reduction -- the part of a

@@ -481,7 +481,8 @@ class MPC_ORD:
             f[rows] = self.eval_population(Xr)
         return f
 
-    def optimize_cmaes_many(self, runs, popsize=None, maxiter=None, maxfevals=None, termination=None, save_paths=None):
+    def optimize_cmaes_many(self, runs, popsize=None, maxiter=None, maxfevals=None, termination=None, save_paths=None,
+                            groups=None):
         """R independent optimize_cmaes runs over this world and car -- `runs` = [(init_states, seed, sigma0), ...], what
         the reference hands to a multiprocessing.Pool, one process per init group (run_mpc_ord.py:83-90) -- advanced in
         LOCKSTEP with one episode launch per generation (optimize_cmaes_lockstep).  Returns a LockstepResult; its `.runs`
@@ -491,7 +492,7 @@ class MPC_ORD:
             ords.append(MPC_ORD(self.world, self.car, init_states, self.designer_horizon,
                                 save_path=None if save_paths is None else save_paths[k], num_samples=self.num_samples))
         return optimize_cmaes_lockstep(ords, [r[1] for r in runs], [r[2] for r in runs], popsize=popsize, maxiter=maxiter,
-                                       maxfevals=maxfevals, termination=termination)
+                                       maxfevals=maxfevals, termination=termination, groups=groups)
 
     def optimize_random_search(self, n_iter=1000, seed=1):
         """mpc_ord.py:47-65: same candidate stream (np.random.rand under np.random.seed), one launch."""
@@ -533,22 +534,38 @@ class LockstepResult:
         self.runs, self.best, self.lockstep = runs, [], True
         self.generation_seconds, self.generation_wall_seconds, self.episodes_per_generation = [], [], []
         self.host_split, self.launch = {}, None
+        self.groups = 1                          # launches per generation (csrc/ocd_cma.c: groups of runs on their own streams)
         self.ranks, self.per_rank = 1, None      # torch.distributed: ranks the runs were dealt over, each rank's timings
 
     def host_split_ms(self):
         return {k: float(np.median(v[-32:]) * 1e3) for k, v in self.host_split.items()}
 
 
-def optimize_cmaes_lockstep(ords, seeds, sigma0s, popsize=None, maxiter=None, maxfevals=None, termination=None, chunk=32):
-    """See _lockstep_local (one process) and _lockstep_over_ranks (torch.distributed): the public entry point."""
+def optimize_cmaes_lockstep(ords, seeds, sigma0s, popsize=None, maxiter=None, maxfevals=None, termination=None, chunk=32,
+                            groups=None):
+    """See _lockstep_local (one process) and _lockstep_over_ranks (torch.distributed): the public entry point.
+    groups: launches per generation (None: two while the whole generation fits one wavefront per SIMD, else one)."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and \
             not any(getattr(o, "_local_only", False) for o in ords):
-        return _lockstep_over_ranks(ords, seeds, sigma0s, popsize, maxiter, maxfevals, termination, chunk)
-    return _lockstep_local(ords, seeds, sigma0s, popsize, maxiter, maxfevals, termination, chunk)
+        return _lockstep_over_ranks(ords, seeds, sigma0s, popsize, maxiter, maxfevals, termination, chunk, groups)
+    return _lockstep_local(ords, seeds, sigma0s, popsize, maxiter, maxfevals, termination, chunk, groups)
 
 
-def _lockstep_local(ords, seeds, sigma0s, popsize=None, maxiter=None, maxfevals=None, termination=None, chunk=32):
+def _lockstep_groups(eng, n_episodes, n_runs):
+    """Two launches per generation while ONE launch of all the runs' episodes would put at most one wavefront on a SIMD --
+    then the halves run side by side and each half's host work hides under the other's kernel; a bigger generation is one
+    launch (two would share SIMDs for nothing)."""
+    if n_runs < 2:
+        return 1
+    import torch
+    cus = torch.cuda.get_device_properties(eng.device).multi_processor_count
+    plan = eng.plan_launch(int(n_episodes), cus)
+    simds = 4 * cus
+    return 2 if plan["workgroups"] * plan["wavefronts_per_workgroup"] <= simds else 1
+
+
+def _lockstep_local(ords, seeds, sigma0s, popsize=None, maxiter=None, maxfevals=None, termination=None, chunk=32, groups=None):
     """MPC_ORD.optimize_cmaes (mpc_ord.py:33-45) for R MPC_ORD objects over the SAME world, car and planner -- their init
     states, seeds and step sizes differ -- with the generation's episodes of ALL runs in one launch.
 
@@ -643,6 +660,17 @@ def _lockstep_local(ords, seeds, sigma0s, popsize=None, maxiter=None, maxfevals=
             a.run_n0, a.run_N, a.run_p0, a.run_reset_phase = run_n0.ctypes.data, run_N.ctypes.data, run_p0.ctypes.data, None
             a.w_pinned, a.index_pinned, a.ret_pinned = w_host.data_ptr(), idx_host.data_ptr(), ret_host.data_ptr()
             a.stream = torch.cuda.current_stream().cuda_stream
+            # Groups (round 6): while the launch fits one wavefront per SIMD (the reference's shapes: 28 runs x 27 episodes =
+            # 756 wavefronts), the runs go out as TWO launches on two streams, side by side on the chip; each half's tells
+            # and asks (0.05 ms of the 0.10 ms a generation spends on the host) run under the other half's kernel
+            # (csrc/ocd_cma.c: ocd_cma_run_many).  Every run's own call sequence, hence its history, is unchanged.
+            n_groups = int(groups) if groups else _lockstep_groups(eng, E_max, R)
+            streams = [torch.cuda.Stream(device=eng.device) for _ in range(n_groups)] if n_groups > 1 else []
+            for st_ in streams:
+                st_.wait_stream(torch.cuda.current_stream())           # (after the baseline evaluations and the uploads above)
+            stream_ptrs = (C.c_void_p * max(n_groups, 1))(*[st_.cuda_stream for st_ in streams])
+            a.n_groups, a.streams = (n_groups if n_groups > 1 else 0), (C.cast(stream_ptrs, C.c_void_p).value if n_groups > 1 else None)
+            res.groups = max(n_groups, 1)
             a.rollout = C.cast(eng.lib.ocd_rollout_indexed, C.c_void_p).value
             a.sync = C.cast(eng.lib.ocd_stream_synchronize, C.c_void_p).value
             a.max_generations = chunk
@@ -720,7 +748,7 @@ def finite_horizon_env(horizon=5, env_seeds=[1], debug=True, extra_inits=False):
     return our_car, world, init_states
 
 
-def _lockstep_over_ranks(ords, seeds, sigma0s, popsize, maxiter, maxfevals, termination, chunk):
+def _lockstep_over_ranks(ords, seeds, sigma0s, popsize, maxiter, maxfevals, termination, chunk, groups=None):
     """optimize_cmaes_lockstep under torch.distributed: rank g makes runs g, g + G, g + 2G, ... in lockstep on its own GPU
     (no collective while they run -- the runs are independent, run_mpc_ord.py:83-90), then one all_gather_object."""
     import torch.distributed as dist
@@ -737,7 +765,7 @@ def _lockstep_over_ranks(ords, seeds, sigma0s, popsize, maxiter, maxfevals, term
                 # (the distributed flag is read through dist.get_world_size(): the local call sees itself as unsharded
                 #  because every MPC_ORD it touches is marked _local_only)
                 local = _lockstep_local([ords[k] for k in mine], [seeds[k] for k in mine], [sigma0s[k] for k in mine],
-                                        popsize, maxiter, maxfevals, termination, chunk)
+                                        popsize, maxiter, maxfevals, termination, chunk, groups)
             for j, k in enumerate(mine):
                 o = ords[k]
                 payload[k] = dict(history=[(np.asarray(w), float(r)) for w, r in o.history], seed=o.history.seed, iter=o.iter,

@@ -34,7 +34,7 @@ def as_array(ptr, shape, dtype):
     return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(n,)).reshape(shape)
 
 
-def make_callbacks(S, nan_below=None, log=None):
+def make_callbacks(S, nan_below=None, log=None, stream_log=None):
     def rollout(scn, init_p, w_p, P, N, e0, e1, ret_p, traj, ctrl, stream):
         init, w, ret = as_array(init_p, (N, 4), np.float32), as_array(w_p, (P, D), np.float32), as_array(ret_p, (e1 - e0,), np.float32)
         for e in range(e0, e1):
@@ -47,6 +47,8 @@ def make_callbacks(S, nan_below=None, log=None):
         idx, ret = as_array(idx_p, (E, 3), np.int32), as_array(ret_p, (E,), np.float32)
         if log is not None:
             log.append(int(E))
+        if stream_log is not None:
+            stream_log.append((stream or 0, int(E), int(idx[0, 0])))
         for e in range(E):
             ret[e] = episode(w[idx[e, 0]], init[idx[e, 1]], int(idx[e, 2]), nan_below)
         return 0
@@ -70,7 +72,7 @@ def run_alone(lib, x0, sigma0, seed, popsize, inits, S, opts, gens, cbs):
     return es, done, why, pending, hist_w[:done + int(pending)], hist_c[:done + int(pending)]
 
 
-def run_many(lib, ess, inits_per_run, S, opts, gens, cbs, active=None):
+def run_many(lib, ess, inits_per_run, S, opts, gens, cbs, active=None, groups=0):
     R = len(ess)
     lams = np.array([es.lam for es in ess], dtype=np.int64)
     run_N = np.array([i.shape[0] for i in inits_per_run], dtype=np.int64)
@@ -98,6 +100,9 @@ def run_many(lib, ess, inits_per_run, S, opts, gens, cbs, active=None):
     a.hist_w, a.hist_cost, a.evaluated = st["hist_w"].ctypes.data, st["hist_c"].ctypes.data, st["evaluated"].ctypes.data
     a.seconds, a.nonfinite, a.episodes_launched = None, st["nonf"].ctypes.data, st["launched"].ctypes.data
     a.stop_flags, a.pending_nan = st["flags"].ctypes.data, st["pending"].ctypes.data
+    if groups:                                                    # (stand-in stream handles: the callbacks only log them)
+        st["streams"] = (C.c_void_p * groups)(*[0x1000 + 16 * k for k in range(groups)])
+        a.n_groups, a.streams = groups, C.cast(st["streams"], C.c_void_p).value
     done = C.c_int64(0)
     assert lib.ocd_cma_run_many(st["es"], C.byref(a), C.byref(done)) == 0
     st["done"] = int(done.value)
@@ -164,6 +169,70 @@ def test_a_nan_cost_hands_only_that_run_back():
         n = min(g0 + 1, a[4].shape[0])
         assert np.array_equal(st["hist_w"][:n, p0:p0 + lam], a[4][:n])
         assert np.array_equal(st["hist_c"][:n, p0:p0 + lam], a[5][:n], equal_nan=True)
+
+
+@pytest.mark.parametrize("groups", [2, 3, 8])
+def test_groups_on_their_own_streams_equal_the_runs_alone(groups):
+    """ABI 7: the runs dealt to G groups, each launching on its own stream and cycling wait -> tell -> ask -> launch by itself
+    (one group's host work under the others' kernels).  Every run still makes exactly the calls it makes alone."""
+    lib = load_cma_library()
+    rng = np.random.default_rng(14)
+    S, gens = 1, 25
+    runs = []
+    for r in range(7):
+        inits = np.ascontiguousarray(rng.uniform(-0.2, 0.2, (1 + r % 2, 4)), dtype=np.float32)
+        runs.append(dict(x0=list(rng.uniform(-1, 1, D)), sigma0=[0.3, 0.05, 0.2, 1e-13, 0.1, 0.4, 0.25][r], seed=21 + r, inits=inits))
+    opts = dict(maxiter=12)
+    slog = []
+    cbs = make_callbacks(S, stream_log=slog)
+    alone = [run_alone(lib, q["x0"], q["sigma0"], q["seed"], None, q["inits"], S, opts, gens, cbs) for q in runs]
+    del slog[:]
+    ess = [NativeCMAES(q["x0"], q["sigma0"], seed=q["seed"]) for q in runs]
+    st = run_many(lib, ess, [q["inits"] for q in runs], S, opts, gens, cbs, groups=groups)
+    assert st["done"] == 12 and not st["active"].any() and not st["pending"].any()
+    for r, (es_a, done_a, why_a, _, hw, hc) in enumerate(alone):
+        p0, lam = int(st["run_p0"][r]), int(st["lams"][r])
+        took_part = st["evaluated"][:, r].astype(bool)
+        assert took_part.sum() == done_a and took_part[:done_a].all()
+        assert np.array_equal(st["hist_w"][:done_a, p0:p0 + lam], hw) and np.array_equal(st["hist_c"][:done_a, p0:p0 + lam], hc)
+        assert {k for i, k in enumerate(STOP_NAMES) if st["flags"][r, i]} == set(why_a)
+        assert np.array_equal(ess[r].mean, es_a.mean) and ess[r].sigma == es_a.sigma and ess[r].gen == done_a
+    # every group launched on its own stream in every generation it had an active run, the groups taking turns
+    G = min(groups, len(runs))
+    used = sorted({s_ for s_, _, _ in slog})
+    assert used == [0x1000 + 16 * k for k in range(G)]
+    first_rows = [int(st["run_p0"][len(runs) * k // G]) for k in range(G)]
+    assert [row for _, _, row in slog[:G]] == first_rows           # generation 0: one launch per group, in group order
+    per_gen = np.array(st["launched"][:12])
+    assert per_gen[0] == int((st["lams"] * st["run_N"]).sum() * S) and sum(e for _, e, _ in slog) == per_gen.sum()
+
+
+def test_a_nan_cost_with_two_groups_hands_that_run_back_and_finishes_what_was_launched():
+    lib = load_cma_library()
+    rng = np.random.default_rng(9)
+    S, gens = 1, 6
+    runs = [dict(x0=[0.5] * D, sigma0=0.3, seed=3 + r, inits=np.ascontiguousarray(rng.uniform(-0.2, 0.2, (2, 4)), dtype=np.float32))
+            for r in range(4)]
+    cbs = make_callbacks(S, nan_below=0.05)
+    opts = dict(maxiter=gens)
+    alone = [run_alone(lib, q["x0"], q["sigma0"], q["seed"], None, q["inits"], S, opts, gens, cbs) for q in runs]
+    ess = [NativeCMAES(q["x0"], q["sigma0"], seed=q["seed"]) for q in runs]
+    st = run_many(lib, ess, [q["inits"] for q in runs], S, opts, gens, cbs, groups=2)
+    assert st["pending"].any()
+    for r, a in enumerate(alone):
+        p0, lam = int(st["run_p0"][r]), int(st["lams"][r])
+        n_eval = int(st["evaluated"][:st["done"], r].sum())         # generations this run was launched in
+        assert st["evaluated"][:n_eval, r].all()
+        if st["pending"][r]:
+            assert ess[r].gen == n_eval - 1 and np.isnan(st["hist_c"][n_eval - 1, p0:p0 + lam]).any()
+            assert a[3] and a[1] == n_eval - 1                      # the run alone met its NaN in the same generation
+        else:
+            assert ess[r].gen == n_eval
+        assert np.array_equal(st["hist_w"][:n_eval, p0:p0 + lam], a[4][:n_eval])
+        assert np.array_equal(st["hist_c"][:n_eval, p0:p0 + lam], a[5][:n_eval], equal_nan=True)
+    # a run of the OTHER group than the first pending one may be one generation ahead, never more
+    gens_done = [int(st["evaluated"][:st["done"], r].sum()) for r in range(4)]
+    assert max(gens_done) - min(gens_done) <= 1 and st["done"] == max(gens_done)
 
 
 def test_bad_arguments_are_refused():

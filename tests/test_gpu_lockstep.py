@@ -59,17 +59,22 @@ def _runs(scn, R, n_inits, seed0):
     return [(list(scn.init_dist.sample(n_inits[r % len(n_inits)], seed=seed0 + r)), 5 + 3 * r, [0.05, 0.2, 0.1][r % 3]) for r in range(R)]
 
 
-@pytest.mark.parametrize("name", ["finite_horizon", "replanning"])
-def test_lockstep_histories_equal_the_runs_alone(hip, name, tmp_path):
+@pytest.mark.parametrize("name,groups,save", [("finite_horizon", None, True), ("replanning", None, True), ("finite_horizon", 1, False),
+                                              ("finite_horizon", 2, False), ("replanning", 2, False), ("replanning", 3, False)])
+def test_lockstep_histories_equal_the_runs_alone(hip, name, groups, save, tmp_path):
+    """groups: launches per generation (round 6: the runs dealt to groups on their own streams, one group's tells and asks
+    under the other's kernel; None = the automatic choice, two for these shapes).  With save paths a native call is one
+    generation (the history on disk is complete after every generation); without, 32 generations go through the pipelined loop."""
     from l4dc_mpc_ocd_amd.interact_drive.experiments.run_mpc_ord import make_mpc_ord
     from l4dc_mpc_ocd_amd.interact_drive.reward_design.mpc_ord import MPC_ORD
     scn = scenarios.SCENARIOS[name](horizon=5)
     base = make_mpc_ord(name, horizon=5, n_inits=1, seed=1)
     runs = _runs(scn, 5, [1, 3, 2], 70)
     runs[3] = (runs[3][0], runs[3][1], 1e-13)                        # a vanishing step size: stops after one generation (tolx)
-    paths = [str(tmp_path / f"run{r}.pkl") for r in range(5)]
-    res = base.optimize_cmaes_many(runs, maxiter=6, save_paths=paths)
+    paths = [str(tmp_path / f"run{r}.pkl") for r in range(5)] if save else None
+    res = base.optimize_cmaes_many(runs, maxiter=6, save_paths=paths, groups=groups)
     assert res.lockstep and len(res.runs) == 5 and len(res.generation_seconds) == 6
+    assert res.groups == (groups or 2)
     E = [9 * len(r[0]) * scn.desc.n_samples for r in runs]
     assert res.episodes_per_generation == [sum(E)] + [sum(E) - E[3]] * 5          # run 3 dropped out after generation 0
     for r, (inits, seed, sigma0) in enumerate(runs):
@@ -84,12 +89,14 @@ def test_lockstep_histories_equal_the_runs_alone(hip, name, tmp_path):
         assert got.history.seed == alone.history.seed == seed and got.iter == alone.iter
         assert np.array_equal(res.best[r], best) and got.es.best_f == alone.es.best_f
         assert got.n_nonfinite == alone.n_nonfinite and len(got.generation_seconds) == len(alone.generation_seconds)
-        with open(paths[r], "rb") as f:                              # the pickle of the run, complete
-            hist = pickle.load(f)
-        assert len(hist) == len(alone.history) and all(np.array_equal(a[0], b[0]) and same(a[1], b[1]) for a, b in zip(hist, alone.history))
+        if save:
+            with open(paths[r], "rb") as f:                          # the pickle of the run, complete
+                hist = pickle.load(f)
+            assert len(hist) == len(alone.history) and all(np.array_equal(a[0], b[0]) and same(a[1], b[1]) for a, b in zip(hist, alone.history))
 
 
-def test_lockstep_redraws_nan_costs_like_the_run_alone(hip):
+@pytest.mark.parametrize("groups", [1, 2, 3])
+def test_lockstep_redraws_nan_costs_like_the_run_alone(hip, groups):
     """A runaway init state (speed -6: no speed floor, simulation_utils.py:14) in ONE of three runs: its NaN candidates are
     redrawn by pycma's rule while the other runs go on; all three histories equal the runs alone."""
     from l4dc_mpc_ocd_amd.interact_drive.reward_design.mpc_ord import MPC_ORD, finite_horizon_env
@@ -99,8 +106,8 @@ def test_lockstep_redraws_nan_costs_like_the_run_alone(hip):
     bad = [np.array([0.0, -0.9, 0.8, PI_2]), np.array([0.02, -0.9, -6.0, PI_2])]
     runs = [(good, 3, 0.3), (bad, 3, 0.3), (good[:1], 4, 0.3)]
     base = MPC_ORD(world, car, good, 15)
-    res = base.optimize_cmaes_many(runs, popsize=16, maxiter=3)
-    assert res.lockstep
+    res = base.optimize_cmaes_many(runs, popsize=16, maxiter=3, groups=groups)
+    assert res.lockstep and res.groups == groups
     for r, (inits, seed, sigma0) in enumerate(runs):
         alone = MPC_ORD(world, car, inits, 15)
         alone.optimize_cmaes(seed=seed, sigma0=sigma0, popsize=16, maxiter=3)
