@@ -34,6 +34,7 @@
 // DESIGN.md section 3; exp/sin/cos from ocd_devmath.h.  No MFMA: there is no dense contraction here.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -226,6 +227,12 @@ mpc_kernel(const KernelParams p)
     const PkConsts pkc = pk_consts();         // constants of the packed exp (ocd_devmath.h), pinned in registers
     ScConsts scc;                             // coefficient pairs of the two-wide sin / cos polynomials: V_ROW latency
     if constexpr (LAT && !(V == V_SEG && asm_chains)) scc = sc_consts();   //   builds (V_SEG with its asm chains runs the scalar ones, see ocd_devmath.h; without them -- the -DOCD_NO_ASM_CHAINS ablation arm -- it calls sincos_pk too)
+    // The latency builds run one wavefront per SIMD (the launcher takes them only then, round 6) and claim theirs: touching
+    // nothing, the clobber raises the kernel's register allocation above half a SIMD's file, so no second wavefront -- of this
+    // launch or of ANOTHER one -- fits beside it (ocd_chunk_kernel.hip does the same).  Two launches on two streams then sit
+    // side by side on different SIMDs instead of sharing them: the lockstep path's groups (csrc/ocd_cma.c: without the claim
+    // the second launch took 1.92 ms beside a 1.18 ms first one, profiles/r06_two_streams.txt).
+    if constexpr (LAT) asm volatile("" ::: "a255");
     OCD_STAMP_DECL
     float G_ret = 0.0f;
     const BumpGeom bg0 = {0.0f, 1.0f, 0.0f, 1.0f};
@@ -1102,7 +1109,11 @@ static hipError_t launch_mpc(const KernelParams &p_in, hipStream_t st)
         // (extra_inits) two of its four SIMDs hold two wavefronts and the workgroup waits for them at every control
         // step -- the reference's validation shapes (27 episodes, K = 6) ran 1.7 x slower than with all K
         // initialisations in one wavefront (round 4, tools/small_shapes.py: H = 6 4.40 -> 2.60 ms, H = 5 2.12 -> 1.26)
-        const bool row_fits_cu = K <= 4 || !seg_cap;
+        // ... and with K <= 4 a compute unit holds floor(4 / K) such workgroups before two wavefronts share a SIMD: 257 ... 341
+        // trajectories at K = 3 fit the SIMD count but not the compute units -- a quarter of them ran two workgroups, 6
+        // wavefronts on 4 SIMDs, and the launch took 1.96 ms where V_SEG (one wavefront per trajectory, any SIMD) takes 1.17
+        // (round 6, tools/two_stream_probe.py 12: 324 episodes of the reference's shape, the lockstep path's launches)
+        const bool row_fits_cu = (K <= 4 && (n <= cus * (4 / K) || !seg_cap)) || !seg_cap;
         if (row_cap && n * K <= simds && row_fits_cu) variant = V_ROW;
         else if (seg_cap && waves_seg <= simds) variant = V_SEG;
         else if (chunk_wins) variant = V_CHUNK;
@@ -1116,10 +1127,11 @@ static hipError_t launch_mpc(const KernelParams &p_in, hipStream_t st)
     else segs = p.segs_used > 0 ? clampi(p.segs_used, 1, G.SEGS) : clampi(ceil_div(n, cus), 1, G.SEGS);
     p.segs_used = segs;
     const unsigned blocks = (unsigned)ceil_div(n, segs);
-    // LAT builds: lane features, few wavefronts per SIMD (measured at config 3's shape: -11 % at one per SIMD,
-    // -2.6 % at two, -1 % at four, +0.4 % at eight), no diagnostics knob set
+    // LAT builds: lane features, ONE wavefront per SIMD (they claim it, see the kernel), no diagnostics knob set.  (Until
+    // round 5 V_SEG took its LAT build up to four per SIMD: -2.6 % at two, -1 % at four at config 3's shape; those sizes
+    // go to the chunked kernel wherever one is compiled.)
     if constexpr (leaf_fast) {
-        if (leaf && variant == V_SEG && blocks <= 4 * simds) {
+        if (leaf && variant == V_SEG && blocks <= simds) {
             p.leaf.grid_in_lds = 1;
             note_launch(p, 3, 0, segs, blocks, 1, HT, 1, 1);
             OCD_LAUNCH((mpc_kernel<HT, NO, L, V_SEG, true, true>), dim3(blocks), dim3(64), leaf_lds, st, p);
@@ -1145,8 +1157,8 @@ static hipError_t launch_mpc(const KernelParams &p_in, hipStream_t st)
     if constexpr (HT > 0) {
         if (variant == V_SEG) {
             if constexpr (HT * 3 <= 64) {
-                note_launch(p, 3, 0, segs, blocks, (lat && blocks <= 4 * simds) ? 1 : 0, HT, 0, 1);
-                if (lat && blocks <= 4 * simds) OCD_LAUNCH((mpc_kernel<HT, NO, L, V_SEG, false, true>), dim3(blocks), dim3(64), 0, st, p);
+                note_launch(p, 3, 0, segs, blocks, (lat && blocks <= simds) ? 1 : 0, HT, 0, 1);
+                if (lat && blocks <= simds) OCD_LAUNCH((mpc_kernel<HT, NO, L, V_SEG, false, true>), dim3(blocks), dim3(64), 0, st, p);
                 else OCD_LAUNCH((mpc_kernel<HT, NO, L, V_SEG>), dim3(blocks), dim3(64), 0, st, p);
             }
             return launch_status(p);

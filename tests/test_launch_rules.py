@@ -56,10 +56,19 @@ RULES = [
     ("merging", 25, 2048, ("chunked", 3, 2, 1024, 1)),
     ("merging", 25, 4096, ("chunked", 5, 4, 1024, 1)),
     ("merging", 25, 32768, ("chunked", 5, 4, 8192, 3)),
-    # the reference's own horizons: DPP rows while trajectories x K fit the SIMDs, then all initialisations in one wavefront
+    # the reference's own horizons: DPP rows (K wavefronts per workgroup, on ONE compute unit) while a compute unit holds
+    # its workgroups one wavefront per SIMD -- floor(4 / K) of them: 256 trajectories at K = 3 --, then all initialisations in
+    # one wavefront (round 6: 258 ... 341 trajectories took the rows and 1.95 ms instead of 1.15, profiles/r06_two_streams.txt)
     ("finite_horizon", 5, 3, ("dpp_rows", 0, 1, 3, 1)),
+    ("finite_horizon", 5, 256, ("dpp_rows", 0, 1, 256, 1)),
+    ("finite_horizon", 5, 257, ("one_wavefront", 0, 1, 257, 1)),
+    ("finite_horizon", 5, 324, ("one_wavefront", 0, 1, 324, 1)),
     ("finite_horizon", 5, 2048, ("one_wavefront", 0, 2, 1024, 1)),
-    ("finite_horizon", 6, 300, ("dpp_rows", 0, 1, 300, 1)),
+    ("finite_horizon", 6, 256, ("dpp_rows", 0, 1, 256, 1)),
+    ("finite_horizon", 6, 300, ("one_wavefront", 0, 1, 300, 1)),
+    # one wavefront per trajectory beyond one per SIMD (no chunked kernel at this horizon): no longer the latency build, which
+    # claims its SIMD (round 6)
+    ("finite_horizon", 5, 8192, ("one_wavefront", 0, 4, 2048, 0)),
     # a horizon without a specialised kernel: run-time H, LDS windows
     ("finite_horizon", 12, 100, ("lds_windows", 0, 1, 100, 0)),
 ]
