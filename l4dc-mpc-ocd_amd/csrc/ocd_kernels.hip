@@ -1137,7 +1137,7 @@ static hipError_t launch_mpc(const KernelParams &p_in, hipStream_t st)
             OCD_LAUNCH((mpc_kernel<HT, NO, L, V_SEG, true, true>), dim3(blocks), dim3(64), leaf_lds, st, p);
             return launch_status(p);
         }
-        if (leaf && variant == V_ROW && (long long)blocks * K <= simds) {
+        if (leaf && variant == V_ROW && (long long)blocks * K <= simds && K <= 4) {
             const size_t lds = (size_t)2 * K * G.SEL_FLOATS * sizeof(float) + leaf_lds;
             p.leaf.grid_in_lds = 1;
             note_launch(p, 2, 0, segs, blocks, 1, HT, 1, K);
@@ -1166,8 +1166,10 @@ static hipError_t launch_mpc(const KernelParams &p_in, hipStream_t st)
         if (variant == V_ROW) {
             const size_t lds = (size_t)2 * K * G.SEL_FLOATS * sizeof(float);
             if constexpr (HT <= 16) {
-                note_launch(p, 2, 0, segs, blocks, (lat && (long long)blocks * K <= simds) ? 1 : 0, HT, 0, K);
-                if (lat && (long long)blocks * K <= simds) OCD_LAUNCH((mpc_kernel<HT, NO, L, V_ROW, false, true>), dim3(blocks), dim3(64 * K), lds, st, p);
+                // (the latency build claims a SIMD per wavefront: a workgroup of more than four cannot be placed at all)
+                const bool row_lat = lat && (long long)blocks * K <= simds && K <= 4;
+                note_launch(p, 2, 0, segs, blocks, row_lat ? 1 : 0, HT, 0, K);
+                if (row_lat) OCD_LAUNCH((mpc_kernel<HT, NO, L, V_ROW, false, true>), dim3(blocks), dim3(64 * K), lds, st, p);
                 else OCD_LAUNCH((mpc_kernel<HT, NO, L, V_ROW>), dim3(blocks), dim3(64 * K), lds, st, p);
             }
             return launch_status(p);
