@@ -265,7 +265,7 @@ def compact_block(b):
            "ms_per_step": b.get("ms_per_step"), "value": b.get("value"),
            "kernel_ms": rf.get("kernel_ms", b.get("kernel_ms")), "binding_frac": rf.get("binding_frac"),
            "parity_ok": parity_ok(b.get("parity"))}
-    for k in ("cma_generation_ms", "eval_weights_ms", "world_step_ms", "runs", "generation_ms_ratio_to_one_run"):
+    for k in ("cma_generation_ms", "eval_weights_ms", "world_step_ms", "runs", "launch_groups", "generation_ms_ratio_to_one_run"):
         if k in b:
             out[k] = b[k]
     if b.get("cpu_baseline"):
@@ -723,7 +723,7 @@ def main():
         ev1.record()
         ev1.synchronize()
         out = {"workload": f"{R} independent CMA-ES runs of {spec['label']} in lockstep: one launch of {E} episodes per generation",
-               "runs": R, "episodes_per_generation": E, "lockstep": bool(res.lockstep),
+               "runs": R, "episodes_per_generation": E, "lockstep": bool(res.lockstep), "launch_groups": int(res.groups),
                "cma_generation_ms": float(np.median(wall)), "cma_generation_native_timers_ms": float(np.median(nat)),
                "kernel_ms": ev0.elapsed_time(ev1) / 10, "launch": eng.last_launch(), "generations_run": len(res.generation_seconds),
                "generations_timed": int(len(wall)), "host_split_ms": res.host_split_ms(),

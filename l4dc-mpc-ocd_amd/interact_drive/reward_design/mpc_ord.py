@@ -552,17 +552,28 @@ def optimize_cmaes_lockstep(ords, seeds, sigma0s, popsize=None, maxiter=None, ma
     return _lockstep_local(ords, seeds, sigma0s, popsize, maxiter, maxfevals, termination, chunk, groups)
 
 
-def _lockstep_groups(eng, n_episodes, n_runs):
-    """Two launches per generation while ONE launch of all the runs' episodes would put at most one wavefront on a SIMD --
-    then the halves run side by side and each half's host work hides under the other's kernel; a bigger generation is one
-    launch (two would share SIMDs for nothing)."""
-    if n_runs < 2:
+def _lockstep_groups(eng, run_episodes):
+    """Two launches per generation while BOTH halves sit on the chip side by side, one wavefront per SIMD -- then each
+    half's host work (tells, asks) hides under the other half's kernel; else one launch.  The latency builds claim their
+    SIMDs, so the halves fit together when their wavefronts fit the SIMDs (one wavefront per workgroup) or their
+    workgroups the compute units (DPP rows: K wavefronts per workgroup, floor(4 / K) workgroups per compute unit).
+    More than two groups do not pay on this runtime: the third stream's launches queue behind the others (measured,
+    profiles/r06_lockstep_groups.txt: 28 runs 1.30 / 1.25 / 2.44 / 3.46 ms per generation with 1 / 2 / 3 / 4 groups)."""
+    R = len(run_episodes)
+    if R < 2:
         return 1
     import torch
     cus = torch.cuda.get_device_properties(eng.device).multi_processor_count
-    plan = eng.plan_launch(int(n_episodes), cus)
-    simds = 4 * cus
-    return 2 if plan["workgroups"] * plan["wavefronts_per_workgroup"] <= simds else 1
+    halves = [int(sum(run_episodes[R * k // 2:R * (k + 1) // 2])) for k in range(2)]
+    wgs, per_wg = 0, 1
+    for e in halves:
+        plan = eng.plan_launch(e, cus)
+        if plan["build_wavefronts_per_simd"] != 1:
+            return 1                                                   # (not a latency build: nothing is claimed)
+        wgs += plan["workgroups"]
+        per_wg = max(per_wg, plan["wavefronts_per_workgroup"])
+    room = 4 * cus if per_wg == 1 else cus * (4 // per_wg)
+    return 2 if wgs <= room else 1
 
 
 def _lockstep_local(ords, seeds, sigma0s, popsize=None, maxiter=None, maxfevals=None, termination=None, chunk=32, groups=None):
@@ -664,7 +675,7 @@ def _lockstep_local(ords, seeds, sigma0s, popsize=None, maxiter=None, maxfevals=
             # 756 wavefronts), the runs go out as TWO launches on two streams, side by side on the chip; each half's tells
             # and asks (0.05 ms of the 0.10 ms a generation spends on the host) run under the other half's kernel
             # (csrc/ocd_cma.c: ocd_cma_run_many).  Every run's own call sequence, hence its history, is unchanged.
-            n_groups = int(groups) if groups else _lockstep_groups(eng, E_max, R)
+            n_groups = int(groups) if groups else _lockstep_groups(eng, (lams * run_N * S).tolist())
             streams = [torch.cuda.Stream(device=eng.device) for _ in range(n_groups)] if n_groups > 1 else []
             for st_ in streams:
                 st_.wait_stream(torch.cuda.current_stream())           # (after the baseline evaluations and the uploads above)

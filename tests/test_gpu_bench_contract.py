@@ -66,7 +66,7 @@ def check_line(d):
     for name in blocks:
         b = d[name]
         assert set(b) <= {"episodes", "ms_per_step", "value", "kernel_ms", "binding_frac", "parity_ok", "cma_generation_ms",
-                          "eval_weights_ms", "world_step_ms", "runs", "generation_ms_ratio_to_one_run", "cpu_value"}, (name, b)
+                          "eval_weights_ms", "world_step_ms", "runs", "launch_groups", "generation_ms_ratio_to_one_run", "cpu_value"}, (name, b)
         assert b["kernel_ms"] > 0 and b["episodes"] > 0 and b["parity_ok"] is True, (name, b)
     assert [d[n]["episodes"] for n in blocks] == [128, 2048, 4096, 16384, 32768, 27, 27, 756, 3]
     # the strong-scaling prediction: rows [N, generation ms, speed-up, efficiency] for N = 1, 2, 4, 8, flagged as a prediction
@@ -148,7 +148,7 @@ def check_detail(d):
     assert c1["cpu_baseline"]["cores"] == 1 and c1["cpu_baseline"]["value"] > 0
     # 28 independent runs of the reference's shape in lockstep: one launch per generation, about the wall time of ONE run
     x28 = d["reference_h5_x28"]
-    assert x28["runs"] == 28 and x28["episodes_per_generation"] == 28 * 27 and x28["lockstep"] is True
+    assert x28["runs"] == 28 and x28["episodes_per_generation"] == 28 * 27 and x28["lockstep"] is True and x28["launch_groups"] == 2
     assert x28["generation_ms_ratio_to_one_run"] <= (1.3 if TIMING else 3.0), x28      # (28 runs one after the other: 28)
     assert x28["kernel_ms"] <= x28["cma_generation_ms"] and x28["cpu_baseline"]["value"] > 0
     assert x28["launch"]["workgroups"] >= 28 and x28["stop_reason"] == ["maxiter"]
