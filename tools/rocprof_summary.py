@@ -87,7 +87,7 @@ def counters_json(round_name, out_dir):
         log = os.path.join(out_dir, f"c{cfg}_stats.log")
         eps = None
         if os.path.exists(log):
-            m = re.search(r'"episodes_per_gpu": (\d+)', open(log).read())
+            m = re.search(r'"episodes_per_gpu":\s*(\d+)', open(log).read())
             eps = int(m.group(1)) if m else None
         key = cfg if cfg.startswith("reference_") else (f"cfg{cfg[:-1]}_share8" if cfg.endswith("s") else f"cfg{cfg}")
         rec[key] = {
