@@ -36,9 +36,15 @@ oracle (the oracle as checker, outside every timed region) on a bounded sample o
 -- returns, world trajectories and applied controls bit for bit, returns within 1e-4 relative, and the kept control
 initialisation of every control step (`argmin_flips`); counts are summed over the ranks.
 
-Prints ONE JSON line (rank 0).  `roofline` follows the contract's hbm/mfma vocabulary although the
-path is bound by fp32 VALU issue: the HBM fraction on algorithmic bytes is reported as
-it is (tiny), and `valu` gives the fp32-vector fraction and the measured VALU issue utilisation.
+Prints ONE JSON line (rank 0) of at most 8 KB (asserted before printing; round 5's had grown to 32 KB and the driver's
+record of it did not parse): the contract's keys, a compact `roofline` (bound / achieved / peak / unit / frac / traffic /
+kernel / kernel_ms / binding / binding_frac ...), `cpu_baseline`, `parity`, `collective`, per extra block six numbers
+(episodes, ms_per_step, value, kernel_ms, binding_frac, parity_ok), and `predicted_strong_scaling` (N = 1: every rank's
+block of a 2 / 4 / 8-way split of configs 4 / 5 timed on this one GPU + the measured gather -- a prediction, flagged as one).
+Everything else -- launch records, host splits, rocprof replay objects, what was sampled and against what -- is written
+whole to `bench_detail.json` beside this file (or $OCD_BENCH_DETAIL); the line names it (`detail`).
+`roofline` follows the contract's hbm/mfma vocabulary although the path is bound by fp32 VALU issue: the HBM
+fraction on algorithmic bytes is reported as it is (tiny), and `binding` / `binding_frac` name the bound that binds.
 """
 import argparse
 import json
