@@ -17,6 +17,15 @@
  *   experiments/replanning_world.py:24-36       ReplanningCarWorld.reset/step
  *   interact_drive/reward_design/mpc_ord.py:67-106  eval_weights_for_init
  *
+ * Pinning.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline / untimed parity legs
+ * load this file; the product never does.  PINNED by every known answer the reference's own tests hold for this path
+ * (tests/test_oracle_kat.py): the four dynamics KATs, the _f / smooth_threshold / smooth_bump doctests, the reward doctest,
+ * both planner KATs with the first-index tie-break, the other_controls layout, the IOC tests' planning car.
+ * PARITY UNPINNED by the reference for ThreeLaneTestCar.features, the scenario constants and every episode return: the
+ * reference holds no test or fixture for them and TensorFlow cannot run here (no oracle/_ref: nothing to compile).  For
+ * those the evidence is second opinions written from the reference's Python (tests/golden/torch_restatement.py,
+ * tests/golden/torch_episode.py: float64 torch), not reference outputs.
+ *
  * Reverse mode: the adjoint below is the tape of the forward ops reversed,
  * with TensorFlow's gradient rules (math_grad.py of TF 2.1):
  *   Minimum(x,y): to x iff x<=y;  Maximum(x,y): to x iff x>=y;
