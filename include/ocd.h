@@ -390,15 +390,17 @@ int32_t ocd_debug_guarded_division(const float *u, const float *n, const float *
 
 /* The kernels evaluate the reward features (merging.py:44-83) and their adjoint through several hand-written forms that
  * must agree bit for bit wherever their preconditions hold (csrc/ocd_device.h: reward_state -- the definition --,
- * reward_one with full / shortened divisions and with sub-skips, reward_fc, reward_fcc, the work-item form).  This entry evaluates ALL of them
+ * reward_one with full / shortened divisions and with sub-skips, reward_fc, reward_fcc, the work-item form, reward_two).  This entry evaluates ALL of them
  * on B caller-supplied world states, so that the tests can hold them to each other form by form:
  *   world_state [B, C, 4]; weights [D];
- *   out   [B, 9, 5]  per form (r, dr/dx, dr/dy, dr/dv, dr/dheading); forms: 0 reward_state, 1 reward_one (straight line, full
+ *   out   [B, 11, 5] per form (r, dr/dx, dr/dy, dr/dv, dr/dheading); forms: 0 reward_state, 1 reward_one (straight line, full
  *                    divisions), 2 reward_one (shortened divisions), 3 reward_one (sub-skips), 4 reward_fc, 5 reward_fc
  *                    (shortened), 6 reward_every, 7 reward_every (shortened), 8 work items (reward_base_grad + feature_item_grad
  *                    through an LDS list, the gradient passes of the chunked kernel's shared-SIMD builds; adjoint only: its r
- *                    repeats form 0; at most two scripted cars);
- *   valid [B, 9]     1 where the form's precondition holds for that state (one active feature, guards of the shortened
+ *                    repeats form 0; at most two scripted cars), 9 / 10 reward_two (two scripted cars: at most two active
+ *                    features per lane -- the latency builds' steps with a lane inside both cars' boxes, round 6; full /
+ *                    reciprocal quotients by the bump widths; adjoint only);
+ *   valid [B, 11]    1 where the form's precondition holds for that state (one active feature, guards of the shortened
  *                    divisions, ...): only those entries are defined.
  * Lane-feature reward with (scripted cars, lanes) in {(1,2), (1,3), (2,2), (2,3), (3,3)}. */
 int32_t ocd_debug_feature_variants(const ocd_scenario *scn, const float *world_state, const float *weights, float *out,

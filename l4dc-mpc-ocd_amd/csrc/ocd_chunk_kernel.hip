@@ -252,7 +252,7 @@ mpc_chunk_kernel(const KernelParams p)
         // one scripted car: the refined reciprocals of its half-widths in this control step (reward_one's FASTDIV form divides by
         // them in every pass) and the lanes whose widths are outside its guard
         BumpRecip br[S][NOA];
-        unsigned long long widths_beyond = 0ull, widths_degenerate = 0ull;
+        unsigned long long widths_beyond = 0ull, widths_degenerate = 0ull, zn_unguarded = 0ull;
 #pragma unroll
         for (int s = 0; s < S; ++s)
 #pragma unroll
@@ -264,6 +264,11 @@ mpc_chunk_kernel(const KernelParams p)
                     br[s][j].rx = refined_recip(bg[s][j].wx);
                     br[s][j].ry = refined_recip(bg[s][j].wy);
                     widths_beyond |= __builtin_amdgcn_ballot_w64(!bump_widths_guarded(bg[s][j]));
+                }
+                if constexpr (lane_feats && NO == 2 && LAT) {   // reward_two's reciprocal quotients (round 6)
+                    br[s][j].rx = refined_recip(bg[s][j].wx);
+                    br[s][j].ry = refined_recip(bg[s][j].wy);
+                    zn_unguarded |= __builtin_amdgcn_ballot_w64(!bump_widths_guarded(bg[s][j]));
                 }
             }
         // a degenerate width (ocd_device.h: bump_widths_degenerate) sends every pass of this control step to the evaluation of
@@ -404,13 +409,14 @@ mpc_chunk_kernel(const KernelParams p)
                     const bool nf = needs_fence(d, xn);
                     const unsigned long long lm = (s >= SL) ? real_mask : live_mask;
                     const unsigned long long mf = __builtin_amdgcn_ballot_w64(nf) & lm;
-                    unsigned long long mc_any = 0ull, multi_f = 0ull, multi_c = 0ull, tiny_n = 0ull;
+                    unsigned long long mc_any = 0ull, multi_f = 0ull, multi_c = 0ull, tiny_n = 0ull, triple = 0ull;
 #pragma unroll
                     for (int j = 0; j < NO; ++j) {
                         const float dx = xn - bg[s][j].cx, dy = yn - bg[s][j].cy;
                         const bool ncx = __builtin_fabsf(dx) < wx1[s][j], ncy = __builtin_fabsf(dy) < wy1[s][j];
                         nc[j] = ncx && ncy;
                         const unsigned long long mj = __builtin_amdgcn_ballot_w64(ncx) & __builtin_amdgcn_ballot_w64(ncy) & lm;
+                        triple |= (mj & mc_any & mf);      // fence and both cars on one lane
                         multi_f |= (mj & mf);
                         multi_c |= (mj & mc_any);
                         mc_any |= mj;
@@ -431,9 +437,24 @@ mpc_chunk_kernel(const KernelParams p)
                             else
                                 rw[s] = reward_one<NO, L, GRAD, false>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], br[s], nc, nf, true,
                                                                        true, q[s], pkc, lgc, lm);
-                        } else if (multi_c != 0ull)
-                            rw[s] = reward_every<NO, L, GRAD, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], q[s], pkc, &lgc, lm);
-                        else
+                        } else if (multi_c != 0ull) {
+                            // a lane inside both boxes: two unit pairs (reward_two, round 6) unless some lane has the fence as
+                            // well, a car's width is outside the reciprocal quotients' guard or a numerator is zero / tiny
+                            if constexpr (NO == 2 && GRAD) {
+                                const float tiny = 7.888609052210118e-31f;         // (tested here: only these steps pay for it)
+                                const unsigned long long zn_tiny =
+                                    (__builtin_amdgcn_ballot_w64(__builtin_fabsf(xn - bg[s][0].cx) < tiny) | __builtin_amdgcn_ballot_w64(__builtin_fabsf(yn - bg[s][0].cy) < tiny) |
+                                     __builtin_amdgcn_ballot_w64(__builtin_fabsf(xn - bg[s][NOA - 1].cx) < tiny) | __builtin_amdgcn_ballot_w64(__builtin_fabsf(yn - bg[s][NOA - 1].cy) < tiny)) & lm;
+                                if (__builtin_expect((triple | zn_unguarded | zn_tiny) != 0ull, 0)) {
+                                    rw[s] = reward_every<NO, L, GRAD, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], q[s], pkc, &lgc, lm);
+                                } else {
+                                    rw[s] = 0.0f;
+                                    reward_two<NO, L, true, true>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], br[s], nc, q[s], pkc, lgc, lm);
+                                }
+                            } else {
+                                rw[s] = reward_every<NO, L, GRAD, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], q[s], pkc, &lgc, lm);
+                            }
+                        } else
                             rw[s] = reward_fc<NO, L, GRAD, GRAD>(d, w, xn, yn, vn[s], sn[s], cn[s], bg[s], nc, q[s], pkc, &lgc, lm);
                         OCD_STAMP(5); OCD_STAMP_COUNT(12);
                     } else {

@@ -7,6 +7,8 @@
 //                  shortened divisions; one scripted car: also (x - cx) / wx by the control step's reciprocals)
 //   reward_fc      fence + at most one car per lane, two packed pairs (full / shortened)
 //   reward_fcc     fence + both cars (two scripted cars), three packed pairs (full / shortened)   [through reward_every]
+//   reward_two     at most two active features per lane (two scripted cars), two packed pairs: the lane's car + the second
+//                  car or the fence (shortened; full / reciprocal quotients by the bump widths)       [adjoint only]
 //   work items     reward_base_grad + one feature_item_grad per active (state, feature), compacted through LDS and evaluated
 //                  64 at a time -- the gradient passes of the chunked kernel's shared-SIMD builds; a state inside both
 //                  cars' boxes as a pair of neighbouring items (adjoint only; one or two scripted cars)
@@ -23,7 +25,7 @@
 
 namespace ocd {
 
-enum { FV_VARIANTS = 9, FV_VALUES = 5 };   // (r, qx, qy, qv, qth) per form
+enum { FV_VARIANTS = 11, FV_VALUES = 5 };   // (r, qx, qy, qv, qth) per form
 
 template <int NO, int L>
 __global__ void __launch_bounds__(64) feature_variants_kernel(const KernelParams p, float *out, int32_t *valid)
@@ -160,6 +162,19 @@ __global__ void __launch_bounds__(64) feature_variants_kernel(const KernelParams
     } else {
 #pragma unroll
         for (int c = 1; c < FV_VALUES; ++c) res[8][c] = 0.0f;
+    }
+    // 9 / 10: at most two active features per lane, two scripted cars (reward_two: the latency builds' both-boxes steps);
+    // adjoint only: r repeats form 0
+    res[9][0] = res[0][0]; res[10][0] = res[0][0];
+    ok[9] = false; ok[10] = false;
+#pragma unroll
+    for (int c = 1; c < FV_VALUES; ++c) { res[9][c] = 0.0f; res[10][c] = 0.0f; }
+    if constexpr (NO == 2) {
+        const bool two_ok = (n_in + (nf ? 1 : 0)) <= 2 && !degenerate && guard_f;
+        reward_two<NO, L, true, false>(d, w, x, y, v, sn, cn, bg, br, nc, q, pkc, lgc, live_mask);
+        res[9][1] = q.qx; res[9][2] = q.qy; res[9][3] = q.qv; res[9][4] = q.qth; ok[9] = two_ok;
+        reward_two<NO, L, true, true>(d, w, x, y, v, sn, cn, bg, br, nc, q, pkc, lgc, live_mask);
+        res[10][1] = q.qx; res[10][2] = q.qy; res[10][3] = q.qv; res[10][4] = q.qth; ok[10] = two_ok && widths_ok && !tiny;
     }
     if (!live) return;
 #pragma unroll

@@ -729,6 +729,142 @@ __device__ __forceinline__ float reward_fcc(const ocd_scenario_desc &d, const fl
     return r;
 }
 
+// ---------------------------------------------------------------- reward, a lane inside BOTH cars' boxes without the fence (NO == 2)
+// Precondition (WAVE-UNIFORM, proved by the caller): no live lane has all three of {fence, car 0's box, car 1's box} active;
+// nc[j] marks the lanes inside car j's box.  Each lane runs TWO pairs of "exp(-1/u + c)" units through one instruction
+// stream (round 6):
+//   pair A  the bumps of ONE car -- car 1 where the lane is inside car 1's box only, else car 0;
+//   pair B  car 1's bumps where the lane is inside BOTH boxes, else the fence's two _f units
+// -- reward_fc with its fence pair lent to the second car on the lanes that need it.  What a lane does not evaluate is
+// exactly 0 with +-0 adjoints (the fence outside its region, a car outside its box: needs_fence / needs_collision1), so
+// the sums only skip +-0 terms and the result is reward_state's bit for bit: on a lane inside both boxes
+// qx = (lanes + car 0) + car 1, qy = (0 + car 0) + car 1 with reduce_max's gradient shared by comparing the two products
+// (the larger takes w, equal ones w / 2 each, the smaller exactly 0); elsewhere reward_fc's sums -- the one car, tied with
+// the other iff its own product is 0, then the fence.  Two packed unit pairs and one shared pair of backward divisions
+// instead of reward_fcc's three + three.  Gradient passes only.  FASTDIV: precondition as reward_fc's.  FASTZN: the four
+// quotients (x - cx_j) / wx_j, (y - cy_j) / wy_j by the control step's refined reciprocals br[j] (quot2_by_recip);
+// precondition: both cars' widths bump_widths_guarded and |x - cx_j|, |y - cy_j| >= 2^-100 on every live lane, both cars.
+template <int NO, int L, bool FASTDIV, bool FASTZN>
+__device__ __forceinline__ void reward_two(const ocd_scenario_desc &d, const float (&w)[OCD_MAX_FEATURES],
+                                           float x, float y, float v, float sn, float cn,
+                                           const BumpGeom (&bg)[NO > 0 ? NO : 1], const BumpRecip (&br)[NO > 0 ? NO : 1],
+                                           const bool (&nc)[NO > 0 ? NO : 1], Q4 &q,
+                                           const PkConsts &pkc, const LaneGradConst<L> &lgc, const unsigned long long live_mask)
+{
+    static_assert(L > 0, "lane-feature reward only");
+    constexpr int J1 = NO > 1 ? 1 : 0;             // (instantiated for NO == 2 only; the index keeps other NO well-formed)
+    static_assert(!FASTZN || FASTDIV, "the reciprocal quotients come with the shortened reciprocals");
+    const float tgt = d.target_speed;
+    const float bound = 4.0f * (tgt * tgt);
+    const float vel = v * sn;
+    const float dv = vel - tgt;
+    const float sq = dv * dv;
+    const bool pass0 = sq <= bound;
+
+    float rl[L], pl[L];
+    float pmin = 0.0f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const float diff = x - d.lane_center[l];
+        rl[l] = diff * -1.0f;
+        const float d2 = rl[l] * rl[l];
+        pl[l] = d2 * 10.0f;
+        pmin = (l == 0) ? pl[0] : min_tf(pmin, pl[l]);
+    }
+
+    const bool both = nc[0] && nc[J1];
+    const bool a1 = nc[J1] && !nc[0];              // pair A is car 1's
+    BumpGeom g = bg[0];
+    g.cx = a1 ? bg[J1].cx : g.cx; g.wx = a1 ? bg[J1].wx : g.wx;
+    g.cy = a1 ? bg[J1].cy : g.cy; g.wy = a1 ? bg[J1].wy : g.wy;
+    v2f ZA, ZB;
+    if constexpr (FASTZN) {
+        const v2f RA = {a1 ? br[J1].rx : br[0].rx, a1 ? br[J1].ry : br[0].ry};
+        ZA = quot2_by_recip(v2f{x - g.cx, y - g.cy}, v2f{g.wx, g.wy}, RA);
+        ZB = quot2_by_recip(v2f{x - bg[J1].cx, y - bg[J1].cy}, v2f{bg[J1].wx, bg[J1].wy}, v2f{br[J1].rx, br[J1].ry});
+    } else {
+        ZA = div2_(v2f{x - g.cx, y - g.cy}, v2f{g.wx, g.wy});
+        ZB = div2_(v2f{x - bg[J1].cx, y - bg[J1].cy}, v2f{bg[J1].wx, bg[J1].wy});
+    }
+    const bool cax = (ZA.x * ZA.x) < 1.0f, cay = (ZA.y * ZA.y) < 1.0f;
+    const bool cbx = (ZB.x * ZB.x) < 1.0f, cby = (ZB.y * ZB.y) < 1.0f;
+    const v2f XCA = {cax ? ZA.x : 0.0f, cay ? ZA.y : 0.0f}, XCB = {cbx ? ZB.x : 0.0f, cby ? ZB.y : 0.0f};
+    const v2f UA = {1.0f - XCA.x * XCA.x, 1.0f - XCA.y * XCA.y};
+    const bool side_p = x > d.fence_lo;
+    const float z = side_p ? x : -x;
+    const float xd = z - d.fence_lo;
+    const bool pos1 = xd > 0.0f;
+    const float uf1 = d.fence_shape * (pos1 ? xd : (0.0f + 0.01f));
+    const float xd2 = d.fence_width - xd;
+    const bool pos2 = xd2 > 0.0f;
+    const float uf2 = d.fence_shape * (pos2 ? xd2 : (0.0f + 0.01f));
+    const v2f UB = {both ? (1.0f - XCB.x * XCB.x) : uf1, both ? (1.0f - XCB.y * XCB.y) : uf2};
+    const float addc = both ? 1.0f : 0.0f;
+    v2f MA, MB, KA, KB;
+    if constexpr (FASTDIV) {
+        recip_pair_guarded(UA, MA, KA);
+        recip_pair_guarded(UB, MB, KB);
+    } else {
+        MA = div2_(splat2(-1.0f), UA);
+        MB = div2_(splat2(-1.0f), UB);
+    }
+    const v2f EA = exp_le1_2(MA + splat2(1.0f), pkc), EB = exp_le1_2(MB + splat2(addc), pkc);
+    if constexpr (!FASTDIV) { KA = div2_(-MA, UA); KB = div2_(-MB, UB); }
+    const float bxa = cax ? EA.x : 0.0f, bya = cay ? EA.y : 0.0f;
+    const float bxb = cbx ? EB.x : 0.0f, byb = cby ? EB.y : 0.0f;
+    const float cola = bxa * bya;
+    const float other = both ? (bxb * byb) : 0.0f;           // the other car's product: exactly 0 where it is not evaluated
+    const float F1 = pos1 ? EB.x : 0.0f, F2 = pos2 ? EB.y : 0.0f;
+    const float den = F1 + F2;
+    const float S = F1 / den;
+    const float ax = (x < 0.0f) ? -x : x;
+
+    const float g_sq = pass0 ? w[0] : 0.0f;
+    const float g_dv = (g_sq * 2.0f) * dv;
+    q.qv = g_dv * sn;
+    const float g_sn = g_dv * v;
+    q.qth = g_sn * cn;
+    const float qx = lane_grad_qx<L>(w, pl, rl, pmin, lgc, live_mask);
+
+    const float w_col = w[L + 2], w_f = w[L + 3];
+    const float share = ((cola == other) ? inv_count(2) : 1.0f) * w_col;
+    const v2f SHA = splat2((cola >= other) ? share : 0.0f), SHB = splat2((other >= cola) ? share : 0.0f);
+    v2f GA, GB;
+    {
+        const v2f BA = {bxa, bya}, BB = {bxb, byb};
+        asm("v_pk_mul_f32 %[g], %[b], %[sh] op_sel:[1,0] op_sel_hi:[0,1]\n"
+            "v_pk_mul_f32 %[g], %[g], %[e]\n"
+            "v_pk_mul_f32 %[g], %[g], %[k]\n"
+            "v_pk_mul_f32 %[g], %[g], 2.0 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]\n"
+            "v_pk_mul_f32 %[g], %[g], %[xc]\n"
+            : [g] "=&v"(GA) : [b] "v"(BA), [sh] "v"(SHA), [e] "v"(EA), [k] "v"(KA), [xc] "v"(XCA));
+        asm("v_pk_mul_f32 %[g], %[b], %[sh] op_sel:[1,0] op_sel_hi:[0,1]\n"
+            "v_pk_mul_f32 %[g], %[g], %[e]\n"
+            "v_pk_mul_f32 %[g], %[g], %[k]\n"
+            "v_pk_mul_f32 %[g], %[g], 2.0 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]\n"
+            "v_pk_mul_f32 %[g], %[g], %[xc]\n"
+            : [g] "=&v"(GB) : [b] "v"(BB), [sh] "v"(SHB), [e] "v"(EB), [k] "v"(KB), [xc] "v"(XCB));
+    }
+    const float g_Ssum = w_f * ax;
+    const float g_ax = w_f * S;
+    const v2f QA = div2_(v2f{cax ? GA.x : 0.0f, cay ? GA.y : 0.0f}, v2f{g.wx, g.wy});
+    const v2f QB = div2_(v2f{both ? (cbx ? GB.x : 0.0f) : g_Ssum, both ? (cby ? GB.y : 0.0f) : -S},
+                         v2f{both ? bg[J1].wx : den, both ? bg[J1].wy : den});
+    const float qx1 = qx + QA.x, qy1 = 0.0f + QA.y;
+    const float g_den = g_Ssum * QB.y;
+    FTape t1, t2;
+    t1.pos = pos1; t1.m = MB.x; t1.e = EB.x; t1.u = uf1;
+    t2.pos = pos2; t2.m = MB.y; t2.e = EB.y; t2.u = uf2;
+    const float ga = f_bwd_gated(QB.x, d.fence_shape, t1, KB.x);
+    const float gb = f_bwd_gated(g_den, d.fence_shape, t1, KB.x);
+    const float gc = f_bwd_gated(g_den, d.fence_shape, t2, KB.y);
+    const float g_z = (ga + gb) + (-gc);
+    const float sgn = (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f);
+    const float qx_f = (qx1 + (side_p ? g_z : -g_z)) + g_ax * sgn;
+    q.qx = both ? (qx1 + QB.x) : qx_f;
+    q.qy = both ? (qy1 + QB.y) : qy1;
+}
+
 // every feature of every lane: the packed evaluation where there is one (two scripted cars), else reward_state
 template <int NO, int L, bool GRAD, bool FASTDIV = false>
 __device__ __forceinline__ float reward_every(const ocd_scenario_desc &d, const float (&w)[OCD_MAX_FEATURES],

@@ -399,14 +399,14 @@ class Engine(DeviceOps):
         return out
 
     def feature_variants(self, world_state, weights):
-        """(out [B, 9, 5], valid [B, 9]): every hand-written form of the reward evaluation on the same world states
+        """(out [B, 11, 5], valid [B, 11]): every hand-written form of the reward evaluation on the same world states
         (include/ocd.h: ocd_debug_feature_variants) -- test support."""
         d = self.desc
         ws = self._to_dev(world_state).reshape(-1, d.n_cars, 4)
         B = ws.shape[0]
         w = self._to_dev(weights).reshape(-1)
-        out = torch.empty((B, 9, 5), dtype=torch.float32, device=self.device)
-        valid = torch.empty((B, 9), dtype=torch.int32, device=self.device)
+        out = torch.empty((B, 11, 5), dtype=torch.float32, device=self.device)
+        valid = torch.empty((B, 11), dtype=torch.int32, device=self.device)
         self._call(self.lib.ocd_debug_feature_variants, self._h, _ptr(ws), _ptr(w), _ptr(out), _ptr(valid), B, self._stream())
         self._wait()
         return out.cpu().numpy(), valid.cpu().numpy().astype(bool)
