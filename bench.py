@@ -730,7 +730,7 @@ def main():
         ev1.synchronize()
         out = {"workload": f"{R} independent CMA-ES runs of {spec['label']} in lockstep: one launch of {E} episodes per generation",
                "runs": R, "episodes_per_generation": E, "lockstep": bool(res.lockstep), "launch_groups": int(res.groups),
-               "cma_generation_ms": float(np.median(wall)), "cma_generation_native_timers_ms": float(np.median(nat)),
+               "host_threads": int(res.host_threads), "cma_generation_ms": float(np.median(wall)), "cma_generation_native_timers_ms": float(np.median(nat)),
                "kernel_ms": ev0.elapsed_time(ev1) / 10, "launch": eng.last_launch(), "generations_run": len(res.generation_seconds),
                "generations_timed": int(len(wall)), "host_split_ms": res.host_split_ms(),
                "value": E / (float(np.median(wall)) * 1e-3), "unit": "episodes/s",

@@ -170,6 +170,9 @@ void ocd_scenario_destroy(ocd_scenario *scn);
  *                (K*H <= 64, wavefront shifts, no workgroup barrier), 4 = a lane owns a chunk of consecutive
  *                horizon steps (long horizons at throughput); a mode the scenario cannot use falls back to 1;
  *   "chunk_size": horizon steps per lane of scan_mode 4 (0 = automatic among the compiled sizes);
+ *   "concurrent_launches": G launches of this handle are in flight on G streams at a time (the lockstep runs' groups,
+ *                ocd_cma.h: ocd_cma_run_many): the launch rules plan each for 1 / G of the device's compute units, so
+ *                that launches of at most one wavefront per SIMD sit side by side (0 / 1 = the whole device, default);
  *   "no_unified_features": 1 = never evaluate a lane's single active feature through the shared path;
  *   "no_feature_skips": 1 = evaluate the collision and fence features even where they are provably
  *                       zero (diagnostics; default 0);

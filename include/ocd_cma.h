@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 #define OCD_CMA_MAX_DIM 64
-#define OCD_CMA_ABI_VERSION 7      /* 7: run_many in groups on several streams (n_groups, streams); 6: the tutorial's weights ln((lambda+1)/2) - ln i over all ranks, active update on by default, set_active, weights; 2: tell returns the non-finite count; resample, stop_state, abi_version; 3: normalise_weights; 4: stop, run; 5: 12 stop rules (noeffectaxis, noeffectcoord), add_evals, run_many */
+#define OCD_CMA_ABI_VERSION 8      /* 8: run_many shares the per-run host work (tells, next deviates, history rows) out to host_threads threads; 7: run_many in groups on several streams (n_groups, streams); 6: the tutorial's weights ln((lambda+1)/2) - ln i over all ranks, active update on by default, set_active, weights; 2: tell returns the non-finite count; resample, stop_state, abi_version; 3: normalise_weights; 4: stop, run; 5: 12 stop rules (noeffectaxis, noeffectcoord), add_evals, run_many */
 #define OCD_CMA_N_STOP 12          /* termination rules of ocd_cma_stop */
 
 typedef struct ocd_cma ocd_cma;
@@ -164,7 +164,9 @@ typedef struct ocd_cma_many_args {
                                    * neighbouring runs, group k launches on streams[k]; each group cycles wait -> tell -> ask -> launch
                                    * by itself and the groups take turns, so one group's host work runs under the others' kernels
                                    * (for launches of at most one wavefront per SIMD: they run side by side) */
-    int32_t reserved;
+    int32_t host_threads;         /* ABI 8 (the field ABI 7 reserved): 0 / 1: the calling thread does all host work.  T > 1 (<= 16): T - 1
+                                   * workers live for the duration of the call and share the runs' tells (and the work that overlaps the
+                                   * kernel) with the caller -- each run is told by one thread on its own state: same results for every T */
     void *const *streams;         /* [n_groups] HIP streams, ordered after whatever produced init_dev */
 } ocd_cma_many_args;
 

@@ -24,7 +24,7 @@ struct ocd_scenario {
     int32_t K;
     int32_t D;
     // per-handle options (ocd_scenario_set_option)
-    int32_t opt_segs = 0, opt_no_skips = 0, opt_scan_mode = 0, opt_no_unify = 0, opt_reset_phase = 0, opt_chunk = 0, opt_no_lat = 0;
+    int32_t opt_segs = 0, opt_no_skips = 0, opt_scan_mode = 0, opt_no_unify = 0, opt_reset_phase = 0, opt_chunk = 0, opt_no_lat = 0, opt_concurrent = 1;
     // The planner's fixed view of the scripted cars' plans (planner_car.py:58-80:
     // plan[j] from index 0, then the assumed default) is a scenario constant; rollouts
     // read it from a small device buffer owned by the handle, one per device.
@@ -141,7 +141,10 @@ int32_t device_state(const ocd_scenario *scn_c, hipStream_t st, ocd::KernelParam
         if (e != hipSuccess || n <= 0) return hip_fail(e, "hipDeviceGetAttribute(multiprocessor count)");
         scn->n_cus[dev] = n;
     }
-    p.n_cus = scn->n_cus[dev];
+    // "concurrent_launches" G: the launch rules plan this launch for 1/G of the compute units, so that G launches on G
+    // streams -- each at most one wavefront per SIMD of ITS share -- sit side by side on the chip
+    p.n_cus = scn->opt_concurrent > 1 ? (scn->n_cus[dev] / scn->opt_concurrent > 0 ? scn->n_cus[dev] / scn->opt_concurrent : 1)
+                                      : scn->n_cus[dev];
     if (!scn->leaf_host.empty()) {
         if (!scn->dev_leaf[dev]) {
             const size_t bytes = scn->leaf_host.size() * sizeof(float);
@@ -242,6 +245,11 @@ int32_t ocd_scenario_set_option(ocd_scenario *scn, const char *name, int32_t val
     if (std::strcmp(name, "chunk_size") == 0) {
         if (value < 0 || value > OCD_MAX_HORIZON) return fail(OCD_ERR_INVALID_ARG, "chunk_size %d out of [0,%d]", value, OCD_MAX_HORIZON);
         scn->opt_chunk = value;
+        return OCD_OK;
+    }
+    if (std::strcmp(name, "concurrent_launches") == 0) {
+        if (value < 0 || value > 16) return fail(OCD_ERR_INVALID_ARG, "concurrent_launches %d out of [0,16]", value);
+        scn->opt_concurrent = value > 1 ? value : 1;
         return OCD_OK;
     }
     if (std::strcmp(name, "no_unified_features") == 0) { scn->opt_no_unify = value ? 1 : 0; return OCD_OK; }

@@ -19,10 +19,13 @@
  * optimisation traces are "parity unpinned" (SURVEY.md 8c); the fitness values are bit-exact.
  *
  * Plain C11, no HIP: libocd_cma.so.  Declared in include/ocd_cma.h. */
-#define _POSIX_C_SOURCE 199309L   /* clock_gettime under -std=c11 */
+#define _POSIX_C_SOURCE 200809L   /* clock_gettime, pthreads under -std=c11 */
 #include "../../include/ocd_cma.h"
 
 #include <math.h>
+#include <pthread.h>
+#include <sched.h>
+#include <stdatomic.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -711,6 +714,146 @@ int32_t ocd_cma_run(ocd_cma *es, const ocd_cma_run_args *a, int64_t *generations
     return 0;
 }
 
+/* ---- host threads for the per-run work of ocd_cma_run_many (ABI 8) ---------------------------------------------------
+ * The tells of a lockstep generation are independent (each run has its own strategy state and random stream) and, at the
+ * reference's shape, the largest item between one kernel's end and the next launch: 28 runs x 3.9 us of 7 x 7
+ * eigendecomposition after a 1.15 ms kernel.  A pool of a->host_threads - 1 workers lives for the duration of one call and
+ * takes runs off a shared counter together with the calling thread; every run is told by exactly one thread, with the
+ * same function on the same state, so nothing about the results depends on the number of threads.
+ * Workers spin (a few milliseconds: longer than an episode kernel of the latency builds) and then sleep on a condition
+ * variable; a job is published by bumping `epoch` to odd (closed: no worker may enter), waiting for the workers still
+ * inside the previous job's claim loop, writing the job, and bumping it to even (open). */
+#define OCD_CMA_MAX_THREADS 16
+#define OCD_CMA_POOL_SPIN_S 4e-3
+typedef void (*cma_run_fn)(void *ctx, int r);
+typedef struct {
+    int n_workers;
+    pthread_t th[OCD_CMA_MAX_THREADS];
+    atomic_uint epoch;
+    atomic_int busy, quit, sleepers;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    cma_run_fn fn;            /* the job: written while epoch is odd and busy == 0 */
+    void *ctx;
+    int r1;
+    atomic_int next, pending; /* next run to claim; runs not finished yet */
+} cma_pool;
+
+static inline void cpu_relax(void)
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    sched_yield();
+#endif
+}
+
+static void pool_claim(cma_pool *p)
+{
+    const cma_run_fn fn = p->fn;
+    void *ctx = p->ctx;
+    const int r1 = p->r1;
+    for (;;) {
+        const int r = atomic_fetch_add(&p->next, 1);
+        if (r >= r1) break;
+        fn(ctx, r);
+        atomic_fetch_sub_explicit(&p->pending, 1, memory_order_release);
+    }
+}
+
+static void *pool_worker(void *arg)
+{
+    cma_pool *p = (cma_pool *)arg;
+    unsigned seen = 0;
+    double idle_since = now_s();
+    for (;;) {
+        unsigned e;
+        unsigned spins = 0;
+        for (;;) {                                           /* wait for an open job this worker has not seen */
+            if (atomic_load(&p->quit)) return NULL;
+            e = atomic_load(&p->epoch);
+            if (e != seen && !(e & 1u)) break;
+            cpu_relax();
+            if ((++spins & 1023u) == 0 && now_s() - idle_since > OCD_CMA_POOL_SPIN_S) {
+                pthread_mutex_lock(&p->mu);
+                atomic_fetch_add(&p->sleepers, 1);
+                for (;;) {
+                    e = atomic_load(&p->epoch);
+                    if (atomic_load(&p->quit) || (e != seen && !(e & 1u))) break;
+                    pthread_cond_wait(&p->cv, &p->mu);
+                }
+                atomic_fetch_sub(&p->sleepers, 1);
+                pthread_mutex_unlock(&p->mu);
+                idle_since = now_s();
+            }
+        }
+        seen = e;
+        atomic_fetch_add(&p->busy, 1);
+        if (atomic_load(&p->epoch) == e) pool_claim(p);      /* (else: closed again under us -- the next job will do) */
+        atomic_fetch_sub(&p->busy, 1);
+        idle_since = now_s();
+    }
+}
+
+static void pool_wake(cma_pool *p)
+{
+    if (atomic_load(&p->sleepers) > 0) {
+        pthread_mutex_lock(&p->mu);
+        pthread_cond_broadcast(&p->cv);
+        pthread_mutex_unlock(&p->mu);
+    }
+}
+
+/* NULL when threads <= 1 or no worker could be started: the caller then runs everything itself */
+static cma_pool *pool_create(int threads)
+{
+    if (threads > OCD_CMA_MAX_THREADS) threads = OCD_CMA_MAX_THREADS;
+    if (threads <= 1) return NULL;
+    cma_pool *p = (cma_pool *)calloc(1, sizeof(cma_pool));
+    if (!p) return NULL;
+    atomic_init(&p->epoch, 0u); atomic_init(&p->busy, 0); atomic_init(&p->quit, 0); atomic_init(&p->sleepers, 0);
+    atomic_init(&p->next, 0); atomic_init(&p->pending, 0);
+    pthread_mutex_init(&p->mu, NULL);
+    pthread_cond_init(&p->cv, NULL);
+    for (int i = 0; i < threads - 1; ++i) {
+        if (pthread_create(&p->th[p->n_workers], NULL, pool_worker, p) != 0) break;
+        p->n_workers += 1;
+    }
+    if (p->n_workers == 0) { pthread_cond_destroy(&p->cv); pthread_mutex_destroy(&p->mu); free(p); return NULL; }
+    return p;
+}
+
+static void pool_destroy(cma_pool *p)
+{
+    if (!p) return;
+    atomic_store(&p->quit, 1);
+    pthread_mutex_lock(&p->mu);
+    pthread_cond_broadcast(&p->cv);
+    pthread_mutex_unlock(&p->mu);
+    for (int i = 0; i < p->n_workers; ++i) pthread_join(p->th[i], NULL);
+    pthread_cond_destroy(&p->cv);
+    pthread_mutex_destroy(&p->mu);
+    free(p);
+}
+
+/* fn(ctx, r) for r in [r0, r1), each r exactly once, on the calling thread and the pool's workers; returns when all are done */
+static void pool_for(cma_pool *p, cma_run_fn fn, void *ctx, int r0, int r1)
+{
+    if (!p || r1 - r0 < 2) {
+        for (int r = r0; r < r1; ++r) fn(ctx, r);
+        return;
+    }
+    atomic_fetch_add(&p->epoch, 1u);                          /* odd: closed */
+    while (atomic_load(&p->busy) != 0) cpu_relax();
+    p->fn = fn; p->ctx = ctx; p->r1 = r1;
+    atomic_store(&p->next, r0);
+    atomic_store(&p->pending, r1 - r0);
+    atomic_fetch_add(&p->epoch, 1u);                          /* even: open */
+    pool_wake(p);
+    pool_claim(p);
+    while (atomic_load_explicit(&p->pending, memory_order_acquire) != 0) cpu_relax();
+}
+
 /* ---- R independent runs in lockstep, one launch per generation -------------------------------------------------------
  * The reference runs one optimisation per init group in a multiprocessing.Pool (run_mpc_ord.py:83-90): R processes, each
  * looping ask -> fitness -> tell on its own population and its own init states.  Here the R strategies advance together
@@ -760,8 +903,46 @@ static void build_group_index(const ocd_cma_many_args *a, ocd_cma *const *es, cm
 
 /* ask -> normalise -> (index) -> launch -> the host work that overlaps the kernel, for the active runs of one group and
  * generation g; t[0..3] += ask, normalise, launch, overlapped seconds */
+/* per-run pieces of a generation that the pool's threads share out (each touches run r's strategy, its rows of the
+ * history / flag arrays and nothing else) */
+typedef struct {
+    ocd_cma *const *es;
+    const ocd_cma_many_args *a;
+    int64_t g;
+    int n;
+    int32_t *status;          /* [R] run_tell: -1 where a call failed */
+    uint8_t *stopped;         /* [R] run_tell: 1 where a termination rule ended run r */
+} run_ctx;
+
+static void run_overlapped(void *ctx, int r)                    /* the next deviates, this generation's history rows */
+{
+    const run_ctx *c = (const run_ctx *)ctx;
+    const ocd_cma_many_args *a = c->a;
+    if (!a->active[r]) return;
+    const int n = c->n;
+    if (a->evaluated) a->evaluated[(size_t)c->g * a->R + r] = 1;
+    ocd_cma_prepare(c->es[r]);
+    if (a->hist_w)
+        for (int k = 0; k < c->es[r]->lam; ++k)
+            row_normalise_once(a->X[r] + (size_t)k * n, n, a->normalise_variant,
+                               a->hist_w + ((size_t)c->g * a->P_rows + a->run_p0[r] + k) * n);
+}
+
+static void run_tell(void *ctx, int r)                          /* tell -> stop */
+{
+    const run_ctx *c = (const run_ctx *)ctx;
+    const ocd_cma_many_args *a = c->a;
+    c->status[r] = 0;
+    c->stopped[r] = 0;
+    if (!a->active[r] || a->pending_nan[r]) return;
+    const int32_t nonfinite = ocd_cma_tell(c->es[r], a->X[r], a->cost[r]);
+    if (nonfinite < 0) { c->status[r] = -1; return; }
+    if (a->nonfinite) a->nonfinite[(size_t)c->g * a->R + r] = nonfinite;
+    if (ocd_cma_stop(c->es[r], a->stop_opts, a->stop_flags + (size_t)r * OCD_CMA_N_STOP) > 0) c->stopped[r] = 1;
+}
+
 static int32_t group_launch(ocd_cma *const *es, const ocd_cma_many_args *a, cma_group *gr, int64_t g, int n, int64_t *ret_off,
-                            double *t)
+                            double *t, cma_pool *pool)
 {
     int n_active = 0;
     for (int r = gr->r0; r < gr->r1; ++r) n_active += a->active[r] != 0;
@@ -782,15 +963,8 @@ static int32_t group_launch(ocd_cma *const *es, const ocd_cma_many_args *a, cma_
     gr->gen = g;
     if (a->episodes_launched) a->episodes_launched[g] += gr->E;
     const double t3 = now_s();
-    for (int r = gr->r0; r < gr->r1; ++r) {                     /* while the GPU works */
-        if (!a->active[r]) continue;
-        if (a->evaluated) a->evaluated[(size_t)g * a->R + r] = 1;
-        ocd_cma_prepare(es[r]);
-        if (a->hist_w)
-            for (int k = 0; k < es[r]->lam; ++k)
-                row_normalise_once(a->X[r] + (size_t)k * n, n, a->normalise_variant,
-                                   a->hist_w + ((size_t)g * a->P_rows + a->run_p0[r] + k) * n);
-    }
+    run_ctx c = {es, a, g, n, NULL, NULL};
+    pool_for(pool, run_overlapped, &c, gr->r0, gr->r1);         /* while the GPU works */
     const double t4 = now_s();
     t[0] += t1 - t0; t[1] += t2 - t1; t[2] += t3 - t2; t[3] += t4 - t3;
     return 0;
@@ -799,7 +973,7 @@ static int32_t group_launch(ocd_cma *const *es, const ocd_cma_many_args *a, cma_
 /* wait -> reduce -> tell -> stop for the group's launch in flight; t[0..2] += wait, reduce, tell seconds;
  * *any_pending |= some run of the group got a NaN cost (left evaluated, not told) */
 static int32_t group_finish(ocd_cma *const *es, const ocd_cma_many_args *a, cma_group *gr, const int64_t *ret_off, double *t,
-                            int *any_pending)
+                            int *any_pending, cma_pool *pool)
 {
     const int64_t g = gr->gen;
     const double t0 = now_s();
@@ -816,12 +990,13 @@ static int32_t group_finish(ocd_cma *const *es, const ocd_cma_many_args *a, cma_
         if (any_nan) { a->pending_nan[r] = 1; *any_pending = 1; }
     }
     const double t2 = now_s();
+    int32_t status[OCD_CMA_MAX_RUNS];
+    uint8_t stopped[OCD_CMA_MAX_RUNS];
+    run_ctx c = {es, a, g, es[gr->r0]->n, status, stopped};
+    pool_for(pool, run_tell, &c, gr->r0, gr->r1);
     for (int r = gr->r0; r < gr->r1; ++r) {
-        if (!a->active[r] || a->pending_nan[r]) continue;
-        const int32_t nonfinite = ocd_cma_tell(es[r], a->X[r], a->cost[r]);
-        if (nonfinite < 0) return -1;
-        if (a->nonfinite) a->nonfinite[(size_t)g * a->R + r] = nonfinite;
-        if (ocd_cma_stop(es[r], a->stop_opts, a->stop_flags + (size_t)r * OCD_CMA_N_STOP) > 0) { a->active[r] = 0; gr->dirty = 1; }
+        if (status[r] != 0) return -1;
+        if (stopped[r]) { a->active[r] = 0; gr->dirty = 1; }
     }
     const double t3 = now_s();
     t[0] += t1 - t0; t[1] += t2 - t1; t[2] += t3 - t2;
@@ -835,7 +1010,7 @@ int32_t ocd_cma_run_many(ocd_cma *const *es, const ocd_cma_many_args *a, int64_t
         !a->run_n0 || !a->run_N || !a->run_p0 || !a->active || !a->X || !a->cost || !a->stop_flags || !a->pending_nan ||
         !a->stop_opts || a->S < 1 || a->N_rows < 1 || a->P_rows < 1 || a->max_generations < 0 ||
         a->normalise_variant < 0 || a->normalise_variant > 1 || a->n_groups < 0 || a->n_groups > OCD_CMA_MAX_GROUPS ||
-        (a->n_groups > 1 && !a->streams)) return -1;
+        (a->n_groups > 1 && !a->streams) || a->host_threads < 0) return -1;
     const int R = a->R;
     int n = 0;
     for (int r = 0; r < R; ++r) {
@@ -872,12 +1047,13 @@ int32_t ocd_cma_run_many(ocd_cma *const *es, const ocd_cma_many_args *a, int64_t
     }
     int32_t err = 0;
     int drain = 0;                             /* a run is pending (NaN cost): finish what is in flight, launch nothing more */
+    cma_pool *pool = pool_create(a->host_threads);   /* NULL: this thread does everything (host_threads 0 / 1) */
     double t_prev = now_s();
     double tl[4] = {0, 0, 0, 0};               /* the launches made for the generation that follows */
     if (a->episodes_launched) a->episodes_launched[0] = 0;
     if (a->evaluated) memset(a->evaluated, 0, (size_t)R);
     for (int k = 0; k < G; ++k) {
-        err = group_launch(es, a, &grp[k], 0, n, ret_off, tl);
+        err = group_launch(es, a, &grp[k], 0, n, ret_off, tl, pool);
         if (err != 0) goto fail;
     }
     for (int64_t g = 0; g < a->max_generations; ++g) {
@@ -894,13 +1070,13 @@ int32_t ocd_cma_run_many(ocd_cma *const *es, const ocd_cma_many_args *a, int64_t
             if (!gr->in_flight || gr->gen != g) continue;   /* (a group without active runs has nothing in flight) */
             any_in_flight = 1;
             int pend = 0;
-            err = group_finish(es, a, gr, ret_off, tf, &pend);
+            err = group_finish(es, a, gr, ret_off, tf, &pend, pool);
             if (err != 0) goto fail;
             if (pend) drain = 1;
             /* this group's next generation goes out before the next group is waited for: its kernel runs while the others'
              * results are reduced and told */
             if (!drain && g + 1 < a->max_generations) {
-                err = group_launch(es, a, gr, g + 1, n, ret_off, tn);
+                err = group_launch(es, a, gr, g + 1, n, ret_off, tn, pool);
                 if (err != 0) goto fail;
             }
         }
@@ -914,10 +1090,12 @@ int32_t ocd_cma_run_many(ocd_cma *const *es, const ocd_cma_many_args *a, int64_t
         for (int k = 0; k < G; ++k) still |= grp[k].in_flight;
         if (!still) break;                                  /* nothing launched for g + 1: pending, the cap, or no active run */
     }
+    pool_destroy(pool);
     return 0;
 fail:                                          /* nothing stays in flight behind an error: the caller frees the buffers */
     for (int k = 0; k < G; ++k)
         if (grp[k].in_flight) { (void)a->sync(grp[k].stream); grp[k].in_flight = 0; }
+    pool_destroy(pool);
     return err;
 }
 

@@ -200,6 +200,62 @@ class Engine(DeviceOps):
         """What a launch of n_problems trajectories would choose (include/ocd.h: ocd_scenario_plan_launch)."""
         return abi.plan_launch(self.lib, self._h, n_problems, n_cus)
 
+    def side_by_side_streams(self, want: int, init_state, probe_episodes: int = 64) -> list:
+        """Up to `want` torch streams on which launches of this handle run SIDE BY SIDE on the chip -- found by
+        measurement, once per engine.  HIP maps its streams onto a few hardware queues (four by default) and two streams
+        that share one run their kernels one after the other: two groups of the lockstep runs then take 2.4 ms per
+        generation instead of 1.2 (profiles/r06_lockstep_streams.txt: the third and fourth stream of PyTorch's pool do).
+        The probe launches `probe_episodes` episodes (the designer's weights from `init_state` [4]) on the streams
+        chosen so far plus one candidate and keeps the candidate when that takes less than 1.45 x one launch alone.
+        The caller has set "concurrent_launches" to `want`, so every probe launch is planned for its share of the chip."""
+        import time
+        have = getattr(self, "_sbs_streams", None)
+        if have is None:
+            have = self._sbs_streams = []
+        if len(have) >= want:
+            return have[:want]
+        d = self.desc
+        init = self._to_dev(np.asarray(init_state, dtype=np.float32).reshape(1, 4))
+        w_row = np.array(d.designer_weights[:max(d.n_features, 1)], dtype=np.float32)
+        P = max(1, int(probe_episodes) // max(1, d.n_samples))
+        w = self._to_dev(np.tile(w_row.reshape(1, -1), (P, 1)))
+        E = P * d.n_samples
+        rets = {}
+
+        def launch(st):
+            ret = rets.get(st.cuda_stream)
+            if ret is None:
+                ret = rets[st.cuda_stream] = torch.empty((E,), dtype=torch.float32, device=self.device)
+            self._call(self.lib.ocd_rollout_episodes, self._h, _ptr(init), _ptr(w), P, 1, 0, E, _ptr(ret), None, None, st.cuda_stream)
+
+        def timed(streams):
+            best = float("inf")
+            for _ in range(2):
+                t0 = time.perf_counter()
+                for st in streams:
+                    launch(st)
+                for st in streams:
+                    st.synchronize()
+                best = min(best, time.perf_counter() - t0)
+            return best
+
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize(self.device)
+            if not have:
+                st0 = torch.cuda.Stream(device=self.device)
+                launch(st0); st0.synchronize()                     # (the first launch on a stream creates its queue)
+                have.append(st0)
+            alone = timed(have[:1])
+            tries = 0
+            while len(have) < want and tries < 3 * want + 4:
+                tries += 1
+                cand = torch.cuda.Stream(device=self.device)
+                launch(cand); cand.synchronize()
+                if timed(have + [cand]) < 1.45 * alone:
+                    have.append(cand)
+        self.side_by_side_probe = dict(alone_ms=alone * 1e3, tried=tries, found=len(have))
+        return have[:want]
+
     def set_leaf_value(self, disc_grid, values, proj_kind: int = 0) -> None:
         """Terminal value of the planner: ValueFeature(disc_grid, v_grids[t]) as leaf_evaluation
         (value_interpolation.py:28-61, naive_planner.py:69-70).  values=None removes it."""

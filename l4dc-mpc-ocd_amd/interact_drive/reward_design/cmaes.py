@@ -318,7 +318,7 @@ class RunManyArgs(C.Structure):
                 ("active", C.c_void_p), ("X", C.c_void_p), ("cost", C.c_void_p), ("hist_w", C.c_void_p),
                 ("hist_cost", C.c_void_p), ("evaluated", C.c_void_p), ("seconds", C.c_void_p), ("nonfinite", C.c_void_p),
                 ("episodes_launched", C.c_void_p), ("stop_flags", C.c_void_p), ("pending_nan", C.c_void_p),
-                ("n_groups", C.c_int32), ("reserved", C.c_int32), ("streams", C.c_void_p)]
+                ("n_groups", C.c_int32), ("host_threads", C.c_int32), ("streams", C.c_void_p)]
 
 
 MAX_RUNS = 256                                                       # OCD_CMA_MAX_RUNS

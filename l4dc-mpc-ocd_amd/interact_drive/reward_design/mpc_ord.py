@@ -6,6 +6,7 @@ torch.distributed initialised (backend "nccl" = RCCL), candidates are sharded ov
 per-episode returns are all-gathered once per call (sharding.py).
 """
 import copyreg
+import os
 import pickle
 import time
 
@@ -482,7 +483,7 @@ class MPC_ORD:
         return f
 
     def optimize_cmaes_many(self, runs, popsize=None, maxiter=None, maxfevals=None, termination=None, save_paths=None,
-                            groups=None):
+                            groups=None, host_threads=None, chunk=None):
         """R independent optimize_cmaes runs over this world and car -- `runs` = [(init_states, seed, sigma0), ...], what
         the reference hands to a multiprocessing.Pool, one process per init group (run_mpc_ord.py:83-90) -- advanced in
         LOCKSTEP with one episode launch per generation (optimize_cmaes_lockstep).  Returns a LockstepResult; its `.runs`
@@ -492,7 +493,8 @@ class MPC_ORD:
             ords.append(MPC_ORD(self.world, self.car, init_states, self.designer_horizon,
                                 save_path=None if save_paths is None else save_paths[k], num_samples=self.num_samples))
         return optimize_cmaes_lockstep(ords, [r[1] for r in runs], [r[2] for r in runs], popsize=popsize, maxiter=maxiter,
-                                       maxfevals=maxfevals, termination=termination, groups=groups)
+                                       maxfevals=maxfevals, termination=termination, groups=groups, host_threads=host_threads,
+                                       chunk=chunk)
 
     def optimize_random_search(self, n_iter=1000, seed=1):
         """mpc_ord.py:47-65: same candidate stream (np.random.rand under np.random.seed), one launch."""
@@ -535,48 +537,73 @@ class LockstepResult:
         self.generation_seconds, self.generation_wall_seconds, self.episodes_per_generation = [], [], []
         self.host_split, self.launch = {}, None
         self.groups = 1                          # launches per generation (csrc/ocd_cma.c: groups of runs on their own streams)
+        self.host_threads = 1                    # threads that shared the tells of a generation (results do not depend on it)
         self.ranks, self.per_rank = 1, None      # torch.distributed: ranks the runs were dealt over, each rank's timings
 
     def host_split_ms(self):
         return {k: float(np.median(v[-32:]) * 1e3) for k, v in self.host_split.items()}
 
 
-def optimize_cmaes_lockstep(ords, seeds, sigma0s, popsize=None, maxiter=None, maxfevals=None, termination=None, chunk=32,
-                            groups=None):
+def optimize_cmaes_lockstep(ords, seeds, sigma0s, popsize=None, maxiter=None, maxfevals=None, termination=None, chunk=None,
+                            groups=None, host_threads=None):
     """See _lockstep_local (one process) and _lockstep_over_ranks (torch.distributed): the public entry point.
-    groups: launches per generation (None: two while the whole generation fits one wavefront per SIMD, else one)."""
+    groups: launches per generation (None: two while the whole generation fits one wavefront per SIMD, else one).
+    host_threads: threads that share the runs' tells inside a native call (None: _lockstep_host_threads; 1: the caller's only).
+    chunk: generations per native call (None: up to 128 while the call's history block stays under 4 MB; the interpreter
+    books the results between calls -- ~1 ms for 28 runs, i.e. 0.03 ms per generation at 32, 0.01 at 128)."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and \
             not any(getattr(o, "_local_only", False) for o in ords):
-        return _lockstep_over_ranks(ords, seeds, sigma0s, popsize, maxiter, maxfevals, termination, chunk, groups)
-    return _lockstep_local(ords, seeds, sigma0s, popsize, maxiter, maxfevals, termination, chunk, groups)
+        return _lockstep_over_ranks(ords, seeds, sigma0s, popsize, maxiter, maxfevals, termination, chunk, groups, host_threads)
+    return _lockstep_local(ords, seeds, sigma0s, popsize, maxiter, maxfevals, termination, chunk, groups, host_threads)
 
 
-def _lockstep_groups(eng, run_episodes):
-    """Two launches per generation while BOTH halves sit on the chip side by side, one wavefront per SIMD -- then each
-    half's host work (tells, asks) hides under the other half's kernel; else one launch.  The latency builds claim their
-    SIMDs, so the halves fit together when their wavefronts fit the SIMDs (one wavefront per workgroup) or their
-    workgroups the compute units (DPP rows: K wavefronts per workgroup, floor(4 / K) workgroups per compute unit).
-    More than two groups do not pay on this runtime: the third stream's launches queue behind the others (measured,
-    profiles/r06_lockstep_groups.txt: 28 runs 1.30 / 1.25 / 2.44 / 3.46 ms per generation with 1 / 2 / 3 / 4 groups)."""
+def _lockstep_groups(eng, run_episodes, cus=None):
+    """Launches per generation: the runs go out as G groups on G streams while every group's launch -- planned for its 1 / G
+    of the compute units ("concurrent_launches") -- is a latency build that fits that share one wavefront per SIMD: the
+    groups then sit side by side on the chip, each cycles wait -> tell -> ask -> launch by itself, and one group's host work
+    hides under the others' kernels.  Four groups where that holds (HIP's four hardware queues: a fifth stream shares one and
+    its launches queue behind another group's, profiles/r06_lockstep_streams.txt), else two, else one launch."""
     R = len(run_episodes)
-    if R < 2:
-        return 1
-    import torch
-    cus = torch.cuda.get_device_properties(eng.device).multi_processor_count
-    halves = [int(sum(run_episodes[R * k // 2:R * (k + 1) // 2])) for k in range(2)]
-    wgs, per_wg = 0, 1
-    for e in halves:
-        plan = eng.plan_launch(e, cus)
-        if plan["build_wavefronts_per_simd"] != 1:
-            return 1                                                   # (not a latency build: nothing is claimed)
-        wgs += plan["workgroups"]
-        per_wg = max(per_wg, plan["wavefronts_per_workgroup"])
-    room = 4 * cus if per_wg == 1 else cus * (4 // per_wg)
-    return 2 if wgs <= room else 1
+    if cus is None:
+        import torch
+        cus = torch.cuda.get_device_properties(eng.device).multi_processor_count
+    for G in (4, 2):
+        if R < G:
+            continue
+        share = cus // G
+        ok = share >= 1
+        for k in range(G):
+            e = int(sum(run_episodes[R * k // G:R * (k + 1) // G]))
+            plan = eng.plan_launch(e, share) if ok else None
+            per_wg = plan["wavefronts_per_workgroup"] if plan else 1
+            room = 4 * share if per_wg == 1 else share * (4 // per_wg)
+            if not plan or plan["build_wavefronts_per_simd"] != 1 or plan["workgroups"] > room:
+                ok = False                                             # (not a latency build: nothing is claimed; or no room)
+                break
+        if ok:
+            return G
+    return 1
 
 
-def _lockstep_local(ords, seeds, sigma0s, popsize=None, maxiter=None, maxfevals=None, termination=None, chunk=32, groups=None):
+def _lockstep_host_threads(n_runs):
+    """Threads of one ocd_cma_run_many call (csrc/ocd_cma.c, ABI 8): the tells of a generation are independent and, at the
+    reference's shape, the largest host item between a kernel's end and the next launch (28 x 3.9 us after a 1.15 ms
+    kernel).  At most four, at most one per four runs, never more than this process's share of the cores less one
+    (torchrun: LOCAL_WORLD_SIZE ranks share the node); OCD_CMA_THREADS overrides.  Results do not depend on it."""
+    env = os.environ.get("OCD_CMA_THREADS", "").strip()
+    if env:
+        return max(1, int(env))
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cores = os.cpu_count() or 1
+    share = max(1, cores // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1)))
+    return max(1, min(4, share - 1, n_runs // 4))
+
+
+def _lockstep_local(ords, seeds, sigma0s, popsize=None, maxiter=None, maxfevals=None, termination=None, chunk=None, groups=None,
+                    host_threads=None):
     """MPC_ORD.optimize_cmaes (mpc_ord.py:33-45) for R MPC_ORD objects over the SAME world, car and planner -- their init
     states, seeds and step sizes differ -- with the generation's episodes of ALL runs in one launch.
 
@@ -621,11 +648,9 @@ def _lockstep_local(ords, seeds, sigma0s, popsize=None, maxiter=None, maxfevals=
         return res
     eng = engines[0]
     lib = load_cma_library()
-    if any(o.save_path is not None for o in ords):
-        # the reference dumps the history after EVERY evaluation (mpc_ord.py:146-148): with a save path a native call is one
-        # generation, so a crash loses at most the generation in flight (the single-run path refuses the native loop for the
-        # same reason).  Histories and pickles are the same either way.
-        chunk = 1
+    # (the reference dumps the history after EVERY evaluation (mpc_ord.py:146-148): with a save path a native call is one
+    #  generation -- chunk = 1 below -- so a crash loses at most the generation in flight (the single-run path refuses the
+    #  native loop for the same reason).  Histories and pickles are the same either way.)
     ess = []
     for o, seed, sigma0 in zip(ords, seeds, sigma0s):                  # the head of optimize_cmaes, per run
         o.history.seed = seed
@@ -644,6 +669,12 @@ def _lockstep_local(ords, seeds, sigma0s, popsize=None, maxiter=None, maxfevals=
     run_p0 = np.concatenate([[0], np.cumsum(lams)[:-1]]).astype(np.int64)
     P_rows, N_rows = int(lams.sum()), int(run_N.sum())
     E_max = int((lams * run_N).sum() * S)
+    if not chunk or int(chunk) < 1:                                    # (0 generations per call would never finish)
+        chunk = int(min(128, max(8, (4 << 20) // (P_rows * D * 8))))
+    chunk = int(chunk)
+    if any(o.save_path is not None for o in ords):
+        chunk = 1
+    concurrent = False
     try:
         with torch.cuda.device(eng.device):
             inits = np.concatenate([np.asarray(o.init_car_states, dtype=np.float32).reshape(-1, 4) for o in ords])
@@ -672,16 +703,29 @@ def _lockstep_local(ords, seeds, sigma0s, popsize=None, maxiter=None, maxfevals=
             a.w_pinned, a.index_pinned, a.ret_pinned = w_host.data_ptr(), idx_host.data_ptr(), ret_host.data_ptr()
             a.stream = torch.cuda.current_stream().cuda_stream
             # Groups (round 6): while the launch fits one wavefront per SIMD (the reference's shapes: 28 runs x 27 episodes =
-            # 756 wavefronts), the runs go out as TWO launches on two streams, side by side on the chip; each half's tells
-            # and asks (0.05 ms of the 0.10 ms a generation spends on the host) run under the other half's kernel
-            # (csrc/ocd_cma.c: ocd_cma_run_many).  Every run's own call sequence, hence its history, is unchanged.
+            # 756 wavefronts), the runs go out as FOUR (else two) launches on as many streams, side by side on the chip; a
+            # group's tells and asks (0.10 ms per generation for all 28 runs on one thread) run under the other groups'
+            # kernels (csrc/ocd_cma.c: ocd_cma_run_many).  Every run's own call sequence, hence its history, is unchanged.
             n_groups = int(groups) if groups else _lockstep_groups(eng, (lams * run_N * S).tolist())
-            streams = [torch.cuda.Stream(device=eng.device) for _ in range(n_groups)] if n_groups > 1 else []
+            streams = []
+            if n_groups > 1:
+                # streams on DIFFERENT hardware queues, found by measurement once per engine (Engine.side_by_side_streams);
+                # each group's launch is planned for its share of the compute units
+                eng.set_option("concurrent_launches", n_groups)
+                concurrent = True
+                streams = list(eng.side_by_side_streams(n_groups, inits[0], int((lams * run_N * S).sum()) // n_groups))
+                if len(streams) < n_groups and not groups:             # (fewer queues than groups: as many groups as streams)
+                    n_groups = 2 if len(streams) >= 2 else 1
+                    streams = streams[:n_groups] if n_groups > 1 else []
+                    eng.set_option("concurrent_launches", n_groups)
+                while len(streams) < n_groups:                         # (a forced group count keeps its count)
+                    streams.append(torch.cuda.Stream(device=eng.device))
             for st_ in streams:
                 st_.wait_stream(torch.cuda.current_stream())           # (after the baseline evaluations and the uploads above)
             stream_ptrs = (C.c_void_p * max(n_groups, 1))(*[st_.cuda_stream for st_ in streams])
             a.n_groups, a.streams = (n_groups if n_groups > 1 else 0), (C.cast(stream_ptrs, C.c_void_p).value if n_groups > 1 else None)
             res.groups = max(n_groups, 1)
+            a.host_threads = res.host_threads = int(host_threads) if host_threads else _lockstep_host_threads(R)
             a.rollout = C.cast(eng.lib.ocd_rollout_indexed, C.c_void_p).value
             a.sync = C.cast(eng.lib.ocd_stream_synchronize, C.c_void_p).value
             a.max_generations = chunk
@@ -733,6 +777,8 @@ def _lockstep_local(ords, seeds, sigma0s, popsize=None, maxiter=None, maxfevals=
                         o.save_history()
             res.launch = eng.last_launch()
     finally:
+        if concurrent:
+            eng.set_option("concurrent_launches", 1)
         for o, es in zip(ords, ess):
             o._eng_fixed = None
             o._init_np_cache = None
@@ -759,7 +805,7 @@ def finite_horizon_env(horizon=5, env_seeds=[1], debug=True, extra_inits=False):
     return our_car, world, init_states
 
 
-def _lockstep_over_ranks(ords, seeds, sigma0s, popsize, maxiter, maxfevals, termination, chunk, groups=None):
+def _lockstep_over_ranks(ords, seeds, sigma0s, popsize, maxiter, maxfevals, termination, chunk, groups=None, host_threads=None):
     """optimize_cmaes_lockstep under torch.distributed: rank g makes runs g, g + G, g + 2G, ... in lockstep on its own GPU
     (no collective while they run -- the runs are independent, run_mpc_ord.py:83-90), then one all_gather_object."""
     import torch.distributed as dist
@@ -776,7 +822,7 @@ def _lockstep_over_ranks(ords, seeds, sigma0s, popsize, maxiter, maxfevals, term
                 # (the distributed flag is read through dist.get_world_size(): the local call sees itself as unsharded
                 #  because every MPC_ORD it touches is marked _local_only)
                 local = _lockstep_local([ords[k] for k in mine], [seeds[k] for k in mine], [sigma0s[k] for k in mine],
-                                        popsize, maxiter, maxfevals, termination, chunk, groups)
+                                        popsize, maxiter, maxfevals, termination, chunk, groups, host_threads)
             for j, k in enumerate(mine):
                 o = ords[k]
                 payload[k] = dict(history=[(np.asarray(w), float(r)) for w, r in o.history], seed=o.history.seed, iter=o.iter,

@@ -72,7 +72,7 @@ def run_alone(lib, x0, sigma0, seed, popsize, inits, S, opts, gens, cbs):
     return es, done, why, pending, hist_w[:done + int(pending)], hist_c[:done + int(pending)]
 
 
-def run_many(lib, ess, inits_per_run, S, opts, gens, cbs, active=None, groups=0):
+def run_many(lib, ess, inits_per_run, S, opts, gens, cbs, active=None, groups=0, threads=0):
     R = len(ess)
     lams = np.array([es.lam for es in ess], dtype=np.int64)
     run_N = np.array([i.shape[0] for i in inits_per_run], dtype=np.int64)
@@ -103,6 +103,7 @@ def run_many(lib, ess, inits_per_run, S, opts, gens, cbs, active=None, groups=0)
     if groups:                                                    # (stand-in stream handles: the callbacks only log them)
         st["streams"] = (C.c_void_p * groups)(*[0x1000 + 16 * k for k in range(groups)])
         a.n_groups, a.streams = groups, C.cast(st["streams"], C.c_void_p).value
+    a.host_threads = threads
     done = C.c_int64(0)
     assert lib.ocd_cma_run_many(st["es"], C.byref(a), C.byref(done)) == 0
     st["done"] = int(done.value)
@@ -233,6 +234,51 @@ def test_a_nan_cost_with_two_groups_hands_that_run_back_and_finishes_what_was_la
     # a run of the OTHER group than the first pending one may be one generation ahead, never more
     gens_done = [int(st["evaluated"][:st["done"], r].sum()) for r in range(4)]
     assert max(gens_done) - min(gens_done) <= 1 and st["done"] == max(gens_done)
+
+
+@pytest.mark.parametrize("groups,threads", [(0, 2), (2, 4), (3, 16), (0, 64)])
+def test_host_threads_change_nothing(groups, threads):
+    """ABI 8: the runs' tells (and the work that overlaps the kernel) shared out to host threads.  Each run is told by one
+    thread on its own strategy state, so populations, costs, stop generations, NaN hand-backs and final states are bit for
+    bit those of the call with one thread -- for every number of threads, with and without launch groups (more threads than
+    the library's cap of 16 are clamped, more than runs idle along)."""
+    lib = load_cma_library()
+    rng = np.random.default_rng(33)
+    S, gens = 1, 60
+    runs = []
+    for r in range(28):                                           # the reference's 28 runs (generalization_data.py:78-84)
+        inits = np.ascontiguousarray(rng.uniform(-0.2, 0.2, (1 + r % 3, 4)), dtype=np.float32)
+        runs.append(dict(x0=list(rng.uniform(-1, 1, D)), sigma0=[0.3, 0.05, 0.2, 1e-13, 0.1, 0.4, 0.25][r % 7], seed=51 + r, inits=inits))
+    opts = dict(maxiter=40)
+    cbs = make_callbacks(S, nan_below=-1.2)                       # (a late NaN in some run: the hand-back path runs too)
+    out = []
+    for t in (1, threads):
+        ess = [NativeCMAES(q["x0"], q["sigma0"], seed=q["seed"]) for q in runs]
+        st = run_many(lib, ess, [q["inits"] for q in runs], S, opts, gens, cbs, groups=groups, threads=t)
+        out.append((st, ess))
+    (s1, e1), (s2, e2) = out
+    assert s1["done"] == s2["done"] and s1["done"] > 0
+    for k in ("hist_w", "hist_c", "evaluated", "nonf", "launched", "active", "pending", "flags"):
+        assert np.array_equal(s1[k], s2[k], equal_nan=True), k
+    for a_, b_ in zip(e1, e2):
+        assert np.array_equal(a_.mean, b_.mean) and a_.sigma == b_.sigma and a_.gen == b_.gen and a_.counteval == b_.counteval
+        assert np.array_equal(a_.C, b_.C) and (a_.best_f == b_.best_f or (np.isnan(a_.best_f) and np.isnan(b_.best_f)))
+
+
+def test_host_threads_many_short_generations():
+    """The pool's hand-over (publish, claim, join) a few thousand times in a row with nothing else between: no lost or doubled run."""
+    lib = load_cma_library()
+    rng = np.random.default_rng(7)
+    runs = [dict(x0=list(rng.uniform(-1, 1, D)), sigma0=0.3, seed=5 + r, inits=np.zeros((1, 4), dtype=np.float32)) for r in range(9)]
+    opts = dict(maxiter=400, tolfun=0.0, tolfunhist=0.0, tolx=0.0, tolstagnation=10 ** 9)
+    cbs = make_callbacks(1)
+    res = []
+    for t in (1, 8):
+        ess = [NativeCMAES(q["x0"], q["sigma0"], popsize=4, seed=q["seed"]) for q in runs]
+        st = run_many(lib, ess, [q["inits"] for q in runs], 1, opts, 400, cbs, threads=t)
+        res.append((st["done"], st["hist_c"].copy(), [es.gen for es in ess], [es.sigma for es in ess]))
+    assert res[0][0] == res[1][0] and res[0][2] == res[1][2] and res[0][3] == res[1][3]
+    assert np.array_equal(res[0][1], res[1][1], equal_nan=True)
 
 
 def test_bad_arguments_are_refused():

@@ -63,7 +63,7 @@ def _runs(scn, R, n_inits, seed0):
                                               ("finite_horizon", 2, False), ("replanning", 2, False), ("replanning", 3, False)])
 def test_lockstep_histories_equal_the_runs_alone(hip, name, groups, save, tmp_path):
     """groups: launches per generation (round 6: the runs dealt to groups on their own streams, one group's tells and asks
-    under the other's kernel; None = the automatic choice, two for these shapes).  With save paths a native call is one
+    under the other's kernel; None = the automatic choice, four for these shapes: each group planned for a quarter of the chip).  With save paths a native call is one
     generation (the history on disk is complete after every generation); without, 32 generations go through the pipelined loop."""
     from l4dc_mpc_ocd_amd.interact_drive.experiments.run_mpc_ord import make_mpc_ord
     from l4dc_mpc_ocd_amd.interact_drive.reward_design.mpc_ord import MPC_ORD
@@ -74,7 +74,7 @@ def test_lockstep_histories_equal_the_runs_alone(hip, name, groups, save, tmp_pa
     paths = [str(tmp_path / f"run{r}.pkl") for r in range(5)] if save else None
     res = base.optimize_cmaes_many(runs, maxiter=6, save_paths=paths, groups=groups)
     assert res.lockstep and len(res.runs) == 5 and len(res.generation_seconds) == 6
-    assert res.groups == (groups or 2)
+    assert res.groups == (groups or 4)                              # (five runs: four groups of one or two)
     E = [9 * len(r[0]) * scn.desc.n_samples for r in runs]
     assert res.episodes_per_generation == [sum(E)] + [sum(E) - E[3]] * 5          # run 3 dropped out after generation 0
     for r, (inits, seed, sigma0) in enumerate(runs):

@@ -137,3 +137,54 @@ def test_argument_checks(lib):
     assert lib.ocd_scenario_plan_launch(None, 10, 0, info) == abi.OCD_ERR_INVALID_ARG
     assert lib.ocd_scenario_plan_launch(h, 10, 0, None) == abi.OCD_ERR_INVALID_ARG
     lib.ocd_scenario_destroy(h)
+
+
+def test_lockstep_group_counts(lib):
+    """How many launches a lockstep generation goes out as (mpc_ord._lockstep_groups): four while every quarter is a latency
+    build that fits its quarter of the compute units one wavefront per SIMD, else two, else one -- planned with each group's
+    share of the compute units, as "concurrent_launches" makes the launcher do (no device needed)."""
+    from l4dc_mpc_ocd_amd.interact_drive.reward_design import mpc_ord
+
+    class Planner:                                                 # Engine.plan_launch on a device-less handle
+        def __init__(self, scn):
+            self.h = C.c_void_p()
+            abi.check(lib, lib.ocd_scenario_create(C.byref(scn.desc), C.byref(self.h)))
+
+        def plan_launch(self, n, n_cus=0):
+            return abi.plan_launch(lib, self.h, n, n_cus)
+
+    ref = Planner(scenarios.finite_horizon(horizon=5))
+    try:
+        assert mpc_ord._lockstep_groups(ref, [27] * 28, cus=256) == 4      # the reference's 28 runs: 4 x 189 one-wavefront workgroups
+        assert mpc_ord._lockstep_groups(ref, [27] * 12, cus=256) == 4
+        assert mpc_ord._lockstep_groups(ref, [27] * 3, cus=256) == 2       # fewer runs than four groups
+        assert mpc_ord._lockstep_groups(ref, [27], cus=256) == 1
+        assert mpc_ord._lockstep_groups(ref, [27] * 40, cus=256) == 4      # 270 per quarter: two trajectories per wavefront (K H = 15 lanes each)
+        assert mpc_ord._lockstep_groups(ref, [27] * 148, cus=256) == 4     # 999 per quarter: four per wavefront, 250 wavefronts
+        assert mpc_ord._lockstep_groups(ref, [27] * 150, cus=256) == 2     # a quarter of 38 runs = 1 026 > 4 x 256; a half = 2 025 fits
+        assert mpc_ord._lockstep_groups(ref, [27] * 160, cus=256) == 1     # 1 080 per quarter, 2 160 per half: past one wavefront per SIMD
+        # every group's plan is a one-wavefront-per-workgroup latency build within its share
+        for G, R in ((4, 28), (4, 148), (2, 150)):
+            e = 27 * R // G
+            p_ = ref.plan_launch(e, 256 // G)
+            assert p_["build_wavefronts_per_simd"] == 1 and p_["workgroups"] * p_["wavefronts_per_workgroup"] <= 4 * (256 // G)
+    finally:
+        lib.ocd_scenario_destroy(ref.h)
+
+
+def test_concurrent_launches_option(lib):
+    """ "concurrent_launches" G is accepted for 0..16 and refused beyond (the plan itself is asked for with the share's
+    compute units: ocd_scenario_plan_launch takes them as an argument)."""
+    scn = scenarios.finite_horizon(horizon=5)
+    h = C.c_void_p()
+    abi.check(lib, lib.ocd_scenario_create(C.byref(scn.desc), C.byref(h)))
+    try:
+        for v in (0, 1, 2, 4, 16):
+            assert lib.ocd_scenario_set_option(h, b"concurrent_launches", v) == abi.OCD_OK
+        assert lib.ocd_scenario_set_option(h, b"concurrent_launches", 17) == abi.OCD_ERR_INVALID_ARG
+        assert lib.ocd_scenario_set_option(h, b"concurrent_launches", -1) == abi.OCD_ERR_INVALID_ARG
+        # a quarter of the chip: 189 trajectories no longer fit DPP rows (3 wavefronts per workgroup, 64 compute units)
+        whole, quarter = abi.plan_launch(lib, h, 189, 256), abi.plan_launch(lib, h, 189, 64)
+        assert whole["mapping"] == "dpp_rows" and quarter["mapping"] == "one_wavefront" and quarter["workgroups"] <= 256
+    finally:
+        lib.ocd_scenario_destroy(h)
