@@ -186,3 +186,55 @@ def test_cli_under_a_launcher_deals_the_runs_over_ranks(hip):
                        capture_output=True, text=True, env=env, timeout=600, cwd=root)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert r.stdout.count("evaluations 19 ") == 6                  # 3 runs x (1 + 2 x 9) evaluations, printed by both ranks
+
+
+def test_side_by_side_streams_and_the_concurrent_launches_option(hip, oracle):
+    """The lockstep groups' streams (Engine.side_by_side_streams): four streams whose launches run side by side -- found by
+    measurement, because HIP maps streams onto a few hardware queues and two streams on one queue run one after the other
+    (profiles/r06_lockstep_streams.txt) -- and the option that plans each launch for its share of the chip.  Results never
+    depend on either: the same episodes with the option at 1 and at 4, on the default stream and on a probed one, equal
+    the oracle's bit for bit."""
+    import time
+    import torch
+    from l4dc_mpc_ocd_amd.engine import Engine
+    scn = scenarios.finite_horizon(horizon=5)
+    eng = Engine(scn, "cuda:0")
+    inits = scn.init_dist.sample(3, seed=8)
+    w = np.stack([scenarios.planner_weights_fp32(c) for c in scn.candidate_weights(63, seed=9)])     # 189 episodes: a quarter of 28 runs
+    ref = oracle.rollout(scn.desc, inits, w)["returns"].reshape(-1)
+    whole = eng.rollout(inits, w)
+    assert eng.last_launch()["mapping"] == "dpp_rows"               # alone: three wavefronts per workgroup, one per compute unit
+    eng.set_option("concurrent_launches", 4)
+    try:
+        quarter = eng.rollout(inits, w)
+        ll = eng.last_launch()
+        assert ll["mapping"] == "one_wavefront" and ll["build_wavefronts_per_simd"] == 1 and ll["workgroups"] <= 256
+        streams = eng.side_by_side_streams(4, inits[0], 189)
+        assert len(streams) == 4 and len({s.cuda_stream for s in streams}) == 4 and eng.side_by_side_probe["found"] == 4
+        assert eng.side_by_side_streams(2, inits[0], 189) == streams[:2]          # cached: no second probe
+        with torch.cuda.stream(streams[3]):
+            on_stream = eng.rollout(inits, w)
+        # the four launches together take about as long as one (side by side), far from four times
+        init_dev, w_dev = eng._to_dev(inits), eng._to_dev(w)
+        rets = [torch.empty(189, dtype=torch.float32, device="cuda:0") for _ in streams]
+
+        def timed(sts):
+            best = float("inf")
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for s, r in zip(sts, rets):
+                    eng._call(eng.lib.ocd_rollout_episodes, eng._h, init_dev.data_ptr(), w_dev.data_ptr(), 63, 3, 0, 189, r.data_ptr(),
+                              None, None, s.cuda_stream)
+                for s in sts:
+                    s.synchronize()
+                best = min(best, time.perf_counter() - t0)
+            return best
+        one, four = timed(streams[:1]), timed(streams)
+        assert four < 1.6 * one, (one, four)
+        for r in rets:
+            assert same(r.cpu().numpy(), ref)
+    finally:
+        eng.set_option("concurrent_launches", 1)
+    for out in (whole, quarter, on_stream):
+        assert same(out["returns"], ref)
