@@ -210,11 +210,12 @@ def test_side_by_side_streams_and_the_concurrent_launches_option(hip, oracle):
         ll = eng.last_launch()
         assert ll["mapping"] == "one_wavefront" and ll["build_wavefronts_per_simd"] == 1 and ll["workgroups"] <= 256
         streams = eng.side_by_side_streams(4, inits[0], 189)
-        assert len(streams) == 4 and len({s.cuda_stream for s in streams}) == 4 and eng.side_by_side_probe["found"] == 4
+        # (four on every box seen so far: HIP's four hardware queues; the lockstep path itself takes what the probe finds)
+        assert 2 <= len(streams) <= 4 and len({s.cuda_stream for s in streams}) == len(streams) == eng.side_by_side_probe["found"]
         assert eng.side_by_side_streams(2, inits[0], 189) == streams[:2]          # cached: no second probe
-        with torch.cuda.stream(streams[3]):
+        with torch.cuda.stream(streams[-1]):
             on_stream = eng.rollout(inits, w)
-        # the four launches together take about as long as one (side by side), far from four times
+        # the launches together take about as long as one (side by side), far from one after the other
         init_dev, w_dev = eng._to_dev(inits), eng._to_dev(w)
         rets = [torch.empty(189, dtype=torch.float32, device="cuda:0") for _ in streams]
 
@@ -231,7 +232,7 @@ def test_side_by_side_streams_and_the_concurrent_launches_option(hip, oracle):
                 best = min(best, time.perf_counter() - t0)
             return best
         one, four = timed(streams[:1]), timed(streams)
-        assert four < 1.6 * one, (one, four)
+        assert four < 1.6 * one, (one, four, len(streams))
         for r in rets:
             assert same(r.cpu().numpy(), ref)
     finally:
