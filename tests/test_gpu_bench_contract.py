@@ -148,7 +148,7 @@ def check_detail(d):
     assert c1["cpu_baseline"]["cores"] == 1 and c1["cpu_baseline"]["value"] > 0
     # 28 independent runs of the reference's shape in lockstep: one launch per generation, about the wall time of ONE run
     x28 = d["reference_h5_x28"]
-    assert x28["runs"] == 28 and x28["episodes_per_generation"] == 28 * 27 and x28["lockstep"] is True and x28["launch_groups"] == 4 and x28["host_threads"] >= 1
+    assert x28["runs"] == 28 and x28["episodes_per_generation"] == 28 * 27 and x28["lockstep"] is True and x28["launch_groups"] in (2, 4) and x28["host_threads"] >= 1   # (four where the probe finds four hardware queues)
     assert x28["generation_ms_ratio_to_one_run"] <= (1.3 if TIMING else 3.0), x28      # (28 runs one after the other: 28)
     assert x28["kernel_ms"] <= x28["cma_generation_ms"] and x28["cpu_baseline"]["value"] > 0
     assert x28["launch"]["workgroups"] >= 28 and x28["stop_reason"] == ["maxiter"]

@@ -74,7 +74,7 @@ def test_lockstep_histories_equal_the_runs_alone(hip, name, groups, save, tmp_pa
     paths = [str(tmp_path / f"run{r}.pkl") for r in range(5)] if save else None
     res = base.optimize_cmaes_many(runs, maxiter=6, save_paths=paths, groups=groups)
     assert res.lockstep and len(res.runs) == 5 and len(res.generation_seconds) == 6
-    assert res.groups == (groups or 4)                              # (five runs: four groups of one or two)
+    assert res.groups == groups if groups else res.groups in (2, 4)   # (five runs: four groups of one or two where the probe finds four queues)
     E = [9 * len(r[0]) * scn.desc.n_samples for r in runs]
     assert res.episodes_per_generation == [sum(E)] + [sum(E) - E[3]] * 5          # run 3 dropped out after generation 0
     for r, (inits, seed, sigma0) in enumerate(runs):
