@@ -547,7 +547,8 @@ class LockstepResult:
 def optimize_cmaes_lockstep(ords, seeds, sigma0s, popsize=None, maxiter=None, maxfevals=None, termination=None, chunk=None,
                             groups=None, host_threads=None):
     """See _lockstep_local (one process) and _lockstep_over_ranks (torch.distributed): the public entry point.
-    groups: launches per generation (None: two while the whole generation fits one wavefront per SIMD, else one).
+    groups: launches per generation (None: _lockstep_groups -- four, else two, while every group's launch is a latency build within
+    its share of the chip, else one).
     host_threads: threads that share the runs' tells inside a native call (None: _lockstep_host_threads; 1: the caller's only).
     chunk: generations per native call (None: up to 128 while the call's history block stays under 4 MB; the interpreter
     books the results between calls -- ~1 ms for 28 runs, i.e. 0.03 ms per generation at 32, 0.01 at 128)."""
