@@ -592,14 +592,19 @@ def _lockstep_host_threads(n_runs):
     reference's shape, the largest host item between a kernel's end and the next launch (28 x 3.9 us after a 1.15 ms
     kernel).  At most four, at most one per four runs, never more than this process's share of the cores less one
     (torchrun: LOCAL_WORLD_SIZE ranks share the node); OCD_CMA_THREADS overrides.  Results do not depend on it."""
-    env = os.environ.get("OCD_CMA_THREADS", "").strip()
-    if env:
-        return max(1, int(env))
+    def _int(name, default):
+        try:
+            return int(os.environ.get(name, "").strip() or default)
+        except ValueError:
+            return default
+    forced = _int("OCD_CMA_THREADS", 0)
+    if forced > 0:
+        return forced
     try:
         cores = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         cores = os.cpu_count() or 1
-    share = max(1, cores // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1)))
+    share = max(1, cores // max(1, _int("LOCAL_WORLD_SIZE", 1)))
     return max(1, min(4, share - 1, n_runs // 4))
 
 

@@ -643,3 +643,24 @@ def test_native_generation_loop_is_the_python_loop():
     assert len(native_hist) == len(py_hist) == 23 * P
     for (wa, ra), (wb, rb) in zip(native_hist, py_hist):
         assert np.array_equal(wa, wb) and (ra == rb or (np.isnan(ra) and np.isnan(rb)))
+
+
+def test_lockstep_host_thread_default(monkeypatch):
+    """How many host threads a lockstep call asks for (mpc_ord._lockstep_host_threads): at most four, one per four runs, never
+    more than this process's share of the cores less one; OCD_CMA_THREADS overrides; nonsense in the environment is ignored."""
+    import os
+    from l4dc_mpc_ocd_amd.interact_drive.reward_design import mpc_ord
+    monkeypatch.delenv("OCD_CMA_THREADS", raising=False)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(16)), raising=False)
+    assert mpc_ord._lockstep_host_threads(28) == 4 and mpc_ord._lockstep_host_threads(9) == 2 and mpc_ord._lockstep_host_threads(3) == 1
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")                    # eight ranks share the 16 cores: two each, one thread to spare
+    assert mpc_ord._lockstep_host_threads(28) == 1
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "not a number")
+    assert mpc_ord._lockstep_host_threads(28) == 4
+    monkeypatch.setenv("OCD_CMA_THREADS", "6")
+    assert mpc_ord._lockstep_host_threads(2) == 6
+    monkeypatch.setenv("OCD_CMA_THREADS", "x")
+    assert mpc_ord._lockstep_host_threads(28) == 4
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: {0}, raising=False)
+    assert mpc_ord._lockstep_host_threads(28) == 1                 # one core: the calling thread only
